@@ -1,0 +1,185 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
+GPU only:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from oracle import rbpf_oracle as orc
+from tests.helpers import oracle_map_from_dump, golden_dump_as_dict
+
+pytestmark = pytest.mark.gpu
+
+Q = 0.1
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from thesis_amd import engine
+    return engine
+
+
+def to_lattice(vals):
+    """float64 log-odds of the reference -> int8 lattice value; asserts the lattice claim."""
+    q = np.rint(np.asarray(vals) / Q)
+    assert np.max(np.abs(np.asarray(vals) - q * Q), initial=0.0) < 1e-9
+    return q.astype(np.int8)
+
+
+def load_dump_into(engine, particle, dump, dim):
+    for (cx, cy), (xs, ys, vals) in dump.items():
+        cells = np.zeros((dim, dim), dtype=np.int8)
+        cells[xs, ys] = to_lattice(vals)
+        engine.set_tile(particle, (cx, cy), cells)
+
+
+def assert_tiles_equal(engine, particle, dump, dim):
+    got = {c: cells for c, cells in engine.tiles(particle)}
+    assert set(got.keys()) == set(dump.keys())
+    for c, (xs, ys, vals) in dump.items():
+        want = np.zeros((dim, dim), dtype=np.int8)
+        want[xs, ys] = to_lattice(vals)
+        if not np.array_equal(got[c], want):
+            bad = np.argwhere(got[c] != want)
+            raise AssertionError(f"tile {c}: {len(bad)} cells differ, first {bad[:5].tolist()} "
+                                 f"got {got[c][tuple(bad[0])]} want {want[tuple(bad[0])]}")
+
+
+def oracle_dump(hm):
+    out = {}
+    for t in hm.tiles:
+        xs, ys = np.nonzero(t.map)
+        out[(float(t.cx), float(t.cy))] = (xs, ys, t.map[xs, ys])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["b", "d"])
+def test_get_odds_at_golden(golden, eng_mod, case):
+    g3, g4 = golden("G3_map_update"), golden("G4_get_odds_at")
+    e = eng_mod.ParticleEngine(2, max_beams=1081, pool_tiles=16)
+    load_dump_into(e, 1, golden_dump_as_dict(g3, case + "_"), e.dim)
+    vals, none = e.get_odds_at(1, g4[case + "_pts"])
+    assert np.array_equal(none, g4[case + "_none"])
+    np.testing.assert_allclose(vals, g4[case + "_vals"], rtol=0, atol=1e-12)
+    # particle 0 still has its empty centre tile only
+    vals0, none0 = e.get_odds_at(0, g4[case + "_pts"])
+    assert np.all(vals0 == 0)
+    e.close()
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_weight_samples_golden(golden, eng_mod, case):
+    g3, g5 = golden("G3_map_update"), golden("G5_sample_weight")
+    P = 3
+    e = eng_mod.ParticleEngine(P, max_beams=1081, pool_tiles=16)
+    for p in range(P):
+        load_dump_into(e, p, golden_dump_as_dict(g3, case + "_"), e.dim)
+    e.set_scan(g5[case + "_ranges"], g5[case + "_angles"])
+    guesses = np.broadcast_to(g5[case + "_guesses"], (P, 30, 3))
+    prs = np.broadcast_to(g5[case + "_prs"], (P, 30))
+    w = e.weight_samples(guesses, prs)
+    for p in range(P):
+        np.testing.assert_allclose(w[p], g5[case + "_w"], rtol=1e-12, atol=1e-9)   # north-star tolerance is 1e-4
+    e.close()
+
+
+@pytest.mark.parametrize("case", list("abcdefg"))
+def test_map_update_golden(golden, eng_mod, case):
+    g = golden("G3_map_update")
+    cs = float(g[case + "_cs"])
+    P = 2
+    e = eng_mod.ParticleEngine(P, max_beams=1081, cell_size=cs, pool_tiles=16)
+    for pose, r in zip(g[case + "_poses"], g[case + "_ranges"]):
+        e.set_scan(r, g[case + "_angles"])
+        e.map_update(np.broadcast_to(pose, (P, 3)))
+    for p in range(P):
+        assert_tiles_equal(e, p, golden_dump_as_dict(g, case + "_"), e.dim)
+    e.close()
+
+
+def test_map_update_random_particles_vs_oracle(eng_mod):
+    """Distinct poses per particle, three scans, compared cell by cell with the oracle."""
+    from thesis_amd.datasets import synthetic
+    rng = np.random.Generator(np.random.PCG64(321))
+    P, B = 6, 1081
+    ang = synthetic.beam_angles(B)
+    e = eng_mod.ParticleEngine(P, max_beams=B, pool_tiles=32)
+    maps = [orc.OracleHybridMap(0.05) for _ in range(P)]
+    base = np.array([[0.0, 0.0, 0.0], [3.1, -2.2, 1.0], [-5.5, 5.0, -2.0], [6.9, 6.9, 0.7], [-7.2, -0.4, 3.0], [0.01, 7.5, -1.57]])
+    for step in range(3):
+        true = base[0] + np.array([0.1 * step, 0.05 * step, 0.02 * step])
+        r = synthetic.cast_scan(true, ang, rng)
+        if step == 1:
+            r[100:140] = 0.0        # invalid returns: "occupied" hit on the start cell
+            r[500:520] = 29.0       # long rays (> 15 m): shortened, end not occupied
+        poses = base + rng.normal(0, 0.02, size=base.shape)
+        e.set_scan(r, ang)
+        e.map_update(poses)
+        sx, sy = orc.scan_xy(r, ang)
+        for p in range(P):
+            maps[p].update(tuple(float(v) for v in poses[p]), sx, sy)
+    for p in range(P):
+        assert_tiles_equal(e, p, oracle_dump(maps[p]), e.dim)
+    c = e.counters()
+    assert c["ray_cells_visited"] > 0 and c["cells_written"] > 0
+    e.close()
+
+
+def test_map_update_ray_cell_count_matches_oracle(eng_mod):
+    from thesis_amd.datasets import synthetic
+    B = 1081
+    ang = synthetic.beam_angles(B)
+    r = synthetic.cast_scan((0.2, 0.1, 0.3), ang, np.random.Generator(np.random.PCG64(1)))
+    hm = orc.OracleHybridMap(0.05)
+    sx, sy = orc.scan_xy(r, ang)
+    hm.update((0.2, 0.1, 0.3), sx, sy)
+    P = 4
+    e = eng_mod.ParticleEngine(P, max_beams=B)
+    e.set_scan(r, ang)
+    e.map_update(np.broadcast_to([0.2, 0.1, 0.3], (P, 3)))
+    c = e.counters()
+    assert c["ray_cells_visited"] == P * hm.cells_visited
+    n_written = sum(int(np.count_nonzero(t.map)) for t in hm.tiles)   # first update from zero: every written cell is non-zero
+    assert c["cells_written"] == P * n_written
+    e.close()
+
+
+@pytest.mark.parametrize("model,mid", [("unicycle", "unicycle"), ("velocity_fr101", "velocity"),
+                                       ("velocity_intelraw", "velocity"), ("absolute", "absolute")])
+def test_imu_update_golden(golden, eng_mod, model, mid):
+    g = golden("G7_imu_update")
+    kw = {}
+    if model == "velocity_intelraw":
+        kw["vel_noise"] = (0.002, 0.05, 0.01, 0.05)      # IntelRawIMUData.py:51-55
+    e = eng_mod.ParticleEngine(5, **kw)
+    for d, dt, p_ref, c_ref in zip(g[model + "_data"], g[model + "_dt"], g[model + "_poses"], g[model + "_covs"]):
+        e.imu_update(mid, d, float(dt))
+    poses, covs = e.poses(), e.covs()
+    for p in range(5):
+        np.testing.assert_allclose(poses[p], g[model + "_poses"][-1], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(covs[p], g[model + "_covs"][-1], rtol=1e-10, atol=1e-18)
+    e.close()
+
+
+def test_map_update_full_size_properties(eng_mod):
+    """BASELINE config 2 size (P=1024, B=1081): identical inputs -> identical maps; every tile equals the
+    oracle's for that pose; repeating the scan saturates but never leaves [-30, 30]."""
+    from thesis_amd.datasets import synthetic
+    P, B = 1024, 1081
+    ang = synthetic.beam_angles(B)
+    r = synthetic.cast_scan((0.0, 0.0, 0.0), ang, np.random.Generator(np.random.PCG64(9)))
+    e = eng_mod.ParticleEngine(P, max_beams=B)
+    e.set_scan(r, ang)
+    for _ in range(3):
+        e.map_update(np.zeros((P, 3)))
+    hm = orc.OracleHybridMap(0.05)
+    sx, sy = orc.scan_xy(r, ang)
+    for _ in range(3):
+        hm.update((0.0, 0.0, 0.0), sx, sy)
+    dump = oracle_dump(hm)
+    for p in (0, 1, 511, 1023):
+        assert_tiles_equal(e, p, dump, e.dim)
+    for _ in range(12):
+        e.map_update(np.zeros((P, 3)))
+    (_, cells), = e.tiles(777)
+    assert cells.min() == -30 and cells.max() == 30
+    e.close()

@@ -1,0 +1,531 @@
+// rbpf_api.hip -- C ABI of librbpf_hip.so (see include/rbpf_hip.h).  Host orchestration only:
+// configuration checks, LUT construction, device memory, stream ordering.  All per-particle work
+// runs in the gfx950 kernels of kernels_*.hip; there is no CPU compute path.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+
+#include "rbpf_internal.h"
+
+using namespace rbpf;
+
+static thread_local std::string g_create_err;
+
+#define HIP_TRY(h, call)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return RBPF_EDEVICE;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+static int fail(rbpf_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+template <typename T>
+static int dev_alloc(rbpf_handle* h, T** out, size_t n) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return RBPF_ENOMEM; }
+    h->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return RBPF_OK;
+}
+#define ALLOC(h, ptr, n) do { int rc_ = dev_alloc(h, &(ptr), (n)); if (rc_) return rc_; } while (0)
+
+static int check_device_error(rbpf_handle* h) {
+    int32_t e = 0;
+    HIP_TRY(h, hipMemcpyAsync(&e, h->v.err, sizeof(e), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (e != 0) {
+        int32_t z = 0;
+        hipMemcpyAsync(h->v.err, &z, sizeof(z), hipMemcpyHostToDevice, h->stream);
+        hipStreamSynchronize(h->stream);
+        const char* what = e == RBPF_ENOMEM ? "tile pool or work-item queue exhausted"
+                         : e == RBPF_ERANGE ? "a pose or beam left the addressable tile lattice (raise lattice_radius)"
+                         : "device-side error";
+        return fail(h, e, what);
+    }
+    return RBPF_OK;
+}
+
+extern "C" {
+
+int rbpf_default_config(rbpf_config* c) {
+    if (!c) return RBPF_EINVAL;
+    memset(c, 0, sizeof(*c));
+    c->n_particles = 1;          // main.py:44
+    c->n_samples = 30;           // robot.py:17
+    c->max_beams = 1081;
+    c->tile_len_m = 40;          // hybridmap.py:68
+    c->cell_size = 0.05;         // hybridmap.py:67
+    c->lattice_radius = 3;
+    c->pool_tiles = 0;
+    c->log_odds_occ = 0.80;      // gridmap.py:20-24
+    c->log_odds_nearby = 0.20;
+    c->max_odds_occ = 3.0;
+    c->log_odds_emp = -0.30;
+    c->min_odds_emp = -3.0;
+    c->quantum = 0.1;
+    c->occupied_threshold = 1.0; // hybridmap.py:18
+    c->max_ray_m = 15.0;         // hybridmap.py:107
+    c->weight_min_range = 0.01;  // robot.py:130
+    c->weight_max_range = 25.0;
+    c->match_min_range = 1e-3;   // hybridmap.py:218
+    c->match_max_range = 11.0;   // hybridmap.py:20
+    c->resample_spread = 200.0;  // main.py:50
+    c->vel_noise[0] = 0.02; c->vel_noise[1] = 0.01; c->vel_noise[2] = 0.2; c->vel_noise[3] = 0.02;  // Freid101IMUData.py:51-55
+    c->device = 0;
+    c->seed = 42;
+    return RBPF_OK;
+}
+
+static bool to_quanta(double val, double q, int& out) {
+    double r = val / q;
+    long n = lround(r);
+    if (fabs(r - (double)n) > 1e-9 || n < -127 || n > 127) return false;
+    out = (int)n;
+    return true;
+}
+
+int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
+    if (!cfg || !out) return fail(nullptr, RBPF_EINVAL, "null argument");
+    *out = nullptr;
+    const rbpf_config& c = *cfg;
+    if (c.n_particles < 1) return fail(nullptr, RBPF_EINVAL, "n_particles must be >= 1");
+    if (c.n_samples < 1 || c.n_samples > 32) return fail(nullptr, RBPF_EINVAL, "n_samples must be in 1..32");
+    if (c.max_beams < 1 || c.max_beams > 8191) return fail(nullptr, RBPF_EINVAL, "max_beams must be in 1..8191");
+    if (c.lattice_radius < 0 || c.lattice_radius > 3) return fail(nullptr, RBPF_EINVAL, "lattice_radius must be in 0..3");
+    if (!(c.cell_size > 0) || c.tile_len_m < 1) return fail(nullptr, RBPF_EINVAL, "cell_size/tile_len_m");   // gridmap.py:29
+    const int dim = (int)llround((double)c.tile_len_m / c.cell_size);                                        // gridmap.py:31
+    if (dim < WIN || dim > 4096 || dim % 4 != 0) return fail(nullptr, RBPF_EINVAL, "tile dimension must be a multiple of 4 in 128..4096 cells");
+    if (!(c.max_ray_m > 0) || c.max_ray_m / c.cell_size + 4 >= dim)
+        return fail(nullptr, RBPF_EINVAL, "max_ray_m must be shorter than one tile");
+    CellConsts cc;
+    if (!(c.quantum > 0) || !to_quanta(c.log_odds_occ, c.quantum, cc.occ) || !to_quanta(c.log_odds_nearby, c.quantum, cc.nearby) ||
+        !to_quanta(c.log_odds_emp, c.quantum, cc.emp) || !to_quanta(c.max_odds_occ, c.quantum, cc.vmax) ||
+        !to_quanta(c.min_odds_emp, c.quantum, cc.vmin))
+        return fail(nullptr, RBPF_EINVAL, "log-odds constants must be integer multiples of quantum within int8");
+    if (cc.emp >= 0 || cc.occ <= 0 || cc.nearby < 0 || cc.vmin > 0 || cc.vmax < 0)
+        return fail(nullptr, RBPF_EINVAL, "log-odds constants have the wrong sign");
+    cc.thr = (int)floor(c.occupied_threshold / c.quantum + 1e-9);
+
+    hipError_t e = hipSetDevice(c.device);
+    if (e != hipSuccess) return fail(nullptr, RBPF_EDEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e) +
+                                     " (librbpf_hip needs an MI355X; there is no CPU path)");
+
+    rbpf_handle* h = new rbpf_handle();
+    h->cfg = c;
+    memset(&h->counters, 0, sizeof(h->counters));
+    DevView& v = h->v;
+    memset(&v, 0, sizeof(v));
+    v.P = c.n_particles; v.K = c.n_samples; v.B = 0; v.dim = dim; v.R = c.lattice_radius; v.L = 2 * v.R + 1;
+    v.pool_tiles = c.pool_tiles > 0 ? c.pool_tiles : 2 * c.n_particles;
+    if (v.pool_tiles < v.P) { delete h; return fail(nullptr, RBPF_EINVAL, "pool_tiles must be >= n_particles"); }
+    v.cs = c.cell_size; v.tile_len = (double)c.tile_len_m;
+    v.quantum = c.quantum;
+    double inv = 1.0 / c.quantum;
+    v.inv_quantum = fabs(inv - round(inv)) < 1e-9 ? round(inv) : 0.0;
+    v.cc = cc;
+    v.w_min_range = c.weight_min_range; v.w_max_range = c.weight_max_range;
+    v.items_cap = raycast_items_cap(c);
+    v.reach = (int)(c.max_ray_m / c.cell_size) + 3;
+
+    // ---- global-index LUT (hybridmap.py:123,136 + gridmap.py:93) -------------------------------
+    {
+        const int half = v.R * dim + dim / 2 + 2;
+        std::vector<uint32_t>& lut = h->h_lut;
+        int g_first = INT32_MAX;
+        for (int g = -half; g <= half; ++g) {
+            double pos = (double)g * v.cs;                       // hybridmap.py:123
+            int lat;
+            if (!tile_of_coord(pos, v.tile_len, v.R, lat)) { if (g_first != INT32_MAX) break; else continue; }
+            double rel = pos - (double)lat * v.tile_len;         // hybridmap.py:136
+            int cidx = trunc_to_int(rel / v.cs + (double)dim / 2.0);   // gridmap.py:93
+            if (cidx < 0 || cidx >= dim) { delete h; return fail(nullptr, RBPF_EINVAL, "cell index formula leaves the tile for this cell_size (the reference would raise IndexError)"); }
+            if (g_first == INT32_MAX) g_first = g;
+            uint32_t ent = ((uint32_t)(lat + v.R) << 16) | (uint32_t)cidx;
+            if (!lut.empty() && ent < lut.back()) { delete h; return fail(nullptr, RBPF_EINVAL, "cell index formula is not monotone for this cell_size"); }
+            lut.push_back(ent);
+        }
+        v.g_min = g_first; v.n_lut = (int)lut.size();
+    }
+
+    int rc = RBPF_OK;
+    auto build = [&]() -> int {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+        for (auto& ev : h->ev) HIP_TRY(h, hipEventCreate(&ev));
+        const size_t P = v.P, LL = (size_t)v.L * v.L, cells = (size_t)dim * dim;
+        uint32_t* d_lut; ALLOC(h, d_lut, h->h_lut.size()); v.lut = d_lut;
+        HIP_TRY(h, hipMemcpy(d_lut, h->h_lut.data(), h->h_lut.size() * 4, hipMemcpyHostToDevice));
+        ALLOC(h, v.px, P); ALLOC(h, v.py, P); ALLOC(h, v.pth, P); ALLOC(h, v.cov, 9 * P); ALLOC(h, v.weight, P);
+        ALLOC(h, v.slot, P); ALLOC(h, v.global_id, P);
+        ALLOC(h, v.tile_tab, P * LL); ALLOC(h, v.pool, (size_t)v.pool_tiles * cells);
+        ALLOC(h, v.tile_bbox, (size_t)v.pool_tiles * 4); ALLOC(h, v.free_stack, v.pool_tiles); ALLOC(h, v.free_top, 1);
+        double* dtmp; uint8_t* btmp;
+        ALLOC(h, dtmp, (size_t)c.max_beams); v.bx = dtmp;
+        ALLOC(h, dtmp, (size_t)c.max_beams); v.by = dtmp;
+        ALLOC(h, dtmp, (size_t)c.max_beams); v.bscale = dtmp;
+        ALLOC(h, btmp, (size_t)c.max_beams); v.bflags = btmp;
+        ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.ray_end, P * (size_t)c.max_beams); ALLOC(h, v.ray_start, 2 * P);
+        ALLOC(h, v.items, P * (size_t)v.items_cap * 4); ALLOC(h, v.n_items, 2);
+        ALLOC(h, v.stats, 8); ALLOC(h, v.err, 1);
+        HIP_TRY(h, hipMemset(v.pool, 0, (size_t)v.pool_tiles * cells));
+        HIP_TRY(h, hipMemset(v.px, 0, P * 8)); HIP_TRY(h, hipMemset(v.py, 0, P * 8)); HIP_TRY(h, hipMemset(v.pth, 0, P * 8));
+        HIP_TRY(h, hipMemset(v.cov, 0, 9 * P * 8));
+        HIP_TRY(h, hipMemset(v.stats, 0, 64)); HIP_TRY(h, hipMemset(v.err, 0, 4)); HIP_TRY(h, hipMemset(v.n_items, 0, 8));
+        // robot.py:20-28 / hybridmap.py:70: weight 1.0, one empty tile centred (0,0) per particle
+        std::vector<double> w(P, 1.0);
+        HIP_TRY(h, hipMemcpy(v.weight, w.data(), P * 8, hipMemcpyHostToDevice));
+        std::vector<int32_t> ids(P), tab(P * LL, -1), fs(v.pool_tiles), bb((size_t)v.pool_tiles * 4);
+        for (size_t p = 0; p < P; ++p) { ids[p] = (int32_t)p; tab[p * LL + (size_t)v.R * v.L + v.R] = (int32_t)p; }
+        for (int t = 0; t < v.pool_tiles; ++t) { bb[4 * t] = INT32_MAX; bb[4 * t + 1] = -1; bb[4 * t + 2] = INT32_MAX; bb[4 * t + 3] = -1; }
+        int32_t top = v.pool_tiles - (int32_t)P;
+        for (int i = 0; i < top; ++i) fs[i] = v.pool_tiles - 1 - i;   // pop order: P, P+1, ...
+        HIP_TRY(h, hipMemcpy(v.slot, ids.data(), P * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(v.global_id, ids.data(), P * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(v.tile_tab, tab.data(), P * LL * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(v.free_stack, fs.data(), (size_t)v.pool_tiles * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(v.free_top, &top, 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(v.tile_bbox, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
+        h->h_pinned_bytes = std::max<size_t>((size_t)c.max_beams * 32, 1 << 16);
+        HIP_TRY(h, hipHostMalloc(&h->h_pinned, h->h_pinned_bytes, hipHostMallocDefault));
+        // the ray-cast kernel needs more than the default 64 KiB of dynamic LDS
+        return RBPF_OK;
+    };
+    rc = build();
+    if (rc != RBPF_OK) { g_create_err = h->err; rbpf_destroy(h); return rc; }
+    *out = h;
+    return RBPF_OK;
+}
+
+int rbpf_destroy(rbpf_handle* h) {
+    if (!h) return RBPF_OK;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->d_guess) hipFree(h->d_guess);
+    if (h->d_prs) hipFree(h->d_prs);
+    if (h->d_w) hipFree(h->d_w);
+    if (h->h_pinned) hipHostFree(h->h_pinned);
+    for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return RBPF_OK;
+}
+
+const char* rbpf_last_error(const rbpf_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int rbpf_set_stream(rbpf_handle* h, void* s) {
+    if (!h) return RBPF_EINVAL;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->own_stream = false;
+    h->stream = static_cast<hipStream_t>(s);
+    return RBPF_OK;
+}
+
+int rbpf_synchronize(rbpf_handle* h) {
+    if (!h) return RBPF_EINVAL;
+    return check_device_error(h);
+}
+
+int rbpf_set_profiling(rbpf_handle* h, int on) {
+    if (!h) return RBPF_EINVAL;
+    h->profiling = on != 0;
+    return RBPF_OK;
+}
+
+int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
+    if (!h || !out) return RBPF_EINVAL;
+    unsigned long long st[8];
+    int32_t top = 0;
+    HIP_TRY(h, hipMemcpyAsync(st, h->v.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&top, h->v.free_top, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    rbpf_counters& c = h->counters;
+    c.scan_updates = h->scan_updates;
+    c.ray_cells_visited = st[ST_RAY_CELLS]; c.cells_written = st[ST_CELLS_WRITTEN];
+    c.cells_gathered = st[ST_GATHERS]; c.slow_cells = st[ST_SLOW_CELLS];
+    c.resample_copies = st[ST_COPIES]; c.bytes_copied = st[ST_COPY_BYTES];
+    c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
+    if (h->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) c.ms_raycast = ms;
+        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) c.ms_weight = ms;
+    }
+    *out = c;
+    return RBPF_OK;
+}
+
+// ---- a1 ---------------------------------------------------------------------------------------------
+int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, int32_t B) {
+    if (!h || !ranges || !angles) return RBPF_EINVAL;
+    if (B < 1 || B > h->cfg.max_beams) return fail(h, RBPF_EINVAL, "n_beams out of range");
+    const rbpf_config& c = h->cfg;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));        // the staging buffer may still be in flight
+    double* sx = static_cast<double*>(h->h_pinned);
+    double* sy = sx + B;
+    double* sc = sy + B;
+    uint8_t* fl = reinterpret_cast<uint8_t*>(sc + B);
+    for (int i = 0; i < B; ++i) {
+        double x = ranges[i] * cos(angles[i]);           // lidar.py:78
+        double y = ranges[i] * sin(angles[i]);           // lidar.py:79
+        double dist = sqrt(x * x + y * y);               // robot.py:129, hybridmap.py:105,217
+        uint8_t f = 0;
+        if (dist < c.weight_max_range && dist > c.weight_min_range) f |= BF_WEIGHT;   // robot.py:130
+        if (dist < c.match_max_range && dist > c.match_min_range) f |= BF_MATCH;      // hybridmap.py:218
+        double s = 1.0;
+        if (dist > c.max_ray_m) { f |= BF_LONG; s = c.max_ray_m / dist; }             // hybridmap.py:107-108
+        sx[i] = x; sy[i] = y; sc[i] = s; fl[i] = f;
+    }
+    DevView& v = h->v;
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.bx), sx, B * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.by), sy, B * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.bscale), sc, B * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(v.bflags), fl, B, hipMemcpyHostToDevice, h->stream));
+    v.B = B;
+    h->have_scan = true;
+    return RBPF_OK;
+}
+
+// ---- a2 ---------------------------------------------------------------------------------------------
+int rbpf_imu_update(rbpf_handle* h, int32_t model, const double* d, double dt_ticks) {
+    if (!h || !d) return RBPF_EINVAL;
+    if (model < 0 || model > 2) return fail(h, RBPF_EINVAL, "unknown motion model");
+    launch_imu_update(h->v, model, d[0], d[1], d[2], dt_ticks, h->cfg.vel_noise, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return RBPF_OK;
+}
+
+// ---- a4 test entry --------------------------------------------------------------------------------------
+static int ensure_sample_buffers(rbpf_handle* h, size_t n) {
+    if (h->d_guess_n >= n) return RBPF_OK;
+    if (h->d_guess) { hipFree(h->d_guess); hipFree(h->d_prs); hipFree(h->d_w); h->d_guess = nullptr; }
+    HIP_TRY(h, hipMalloc((void**)&h->d_guess, n * 3 * 8));
+    HIP_TRY(h, hipMalloc((void**)&h->d_prs, n * 8));
+    HIP_TRY(h, hipMalloc((void**)&h->d_w, n * 8));
+    h->d_guess_n = n;
+    return RBPF_OK;
+}
+
+int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs, int32_t K, double* out_w) {
+    if (!h || !guesses || !prs || !out_w) return RBPF_EINVAL;
+    if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
+    if (K < 1 || K > 32) return fail(h, RBPF_EINVAL, "n_samples must be in 1..32");
+    const size_t n = (size_t)h->v.P * K;
+    int rc = ensure_sample_buffers(h, n);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_guess, guesses, n * 3 * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_prs, prs, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->profiling) hipEventRecord(h->ev[2], h->stream);
+    launch_weight_samples(h->v, h->d_guess, h->d_prs, K, h->d_w, h->stream);
+    if (h->profiling) hipEventRecord(h->ev[3], h->stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_w, h->d_w, n * 8, hipMemcpyDeviceToHost, h->stream));
+    return check_device_error(h);
+}
+
+// ---- a5 test entry --------------------------------------------------------------------------------------
+static int run_map_update(rbpf_handle* h) {
+    DevView& v = h->v;
+    HIP_TRY(h, hipMemsetAsync(v.stats, 0, 2 * sizeof(unsigned long long), h->stream));   // ray cells, cells written
+    HIP_TRY(h, hipMemsetAsync(&v.stats[ST_SLOW_CELLS], 0, sizeof(unsigned long long), h->stream));
+    static bool attr_set = false;
+    (void)attr_set;
+    launch_map_update(v, h->stream, h->profiling ? h->ev[0] : nullptr, h->profiling ? h->ev[1] : nullptr);
+    HIP_TRY(h, hipGetLastError());
+    h->scan_updates++;
+    return RBPF_OK;
+}
+
+int rbpf_map_update(rbpf_handle* h, const double* poses) {
+    if (!h) return RBPF_EINVAL;
+    if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
+    DevView& v = h->v;
+    const size_t P = v.P;
+    if (poses) {
+        std::vector<double> soa(3 * P);
+        for (size_t p = 0; p < P; ++p) { soa[p] = poses[3 * p]; soa[P + p] = poses[3 * p + 1]; soa[2 * P + p] = poses[3 * p + 2]; }
+        HIP_TRY(h, hipMemcpyAsync(v.upd_pose, soa.data(), 3 * P * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(v.upd_pose, v.px, P * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(v.upd_pose + P, v.py, P * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(v.upd_pose + 2 * P, v.pth, P * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+    int rc = run_map_update(h);
+    if (rc) return rc;
+    return check_device_error(h);
+}
+
+// ---- not yet implemented in this build step (declared so that the ABI is complete) ----------------------
+int rbpf_scan_update(rbpf_handle* h, int32_t, const double*, int32_t, const double*, const double*) {
+    return fail(h, RBPF_ESTATE, "rbpf_scan_update: not built yet");
+}
+int rbpf_match_scan(rbpf_handle* h, const double*, int32_t, const double*, int32_t, const double*, int32_t,
+                    const double*, double*, double*, double*) {
+    return fail(h, RBPF_ESTATE, "rbpf_match_scan: not built yet");
+}
+int rbpf_match_inputs(rbpf_handle* h, int32_t, const double*, double*, int32_t*, double*, int32_t*, int32_t) {
+    return fail(h, RBPF_ESTATE, "rbpf_match_inputs: not built yet");
+}
+int rbpf_resample(rbpf_handle* h, double, int32_t*, int32_t*) { return fail(h, RBPF_ESTATE, "rbpf_resample: not built yet"); }
+int rbpf_export_weights(rbpf_handle* h, void*, int32_t) { return fail(h, RBPF_ESTATE, "not built yet"); }
+int rbpf_resample_indices_global(rbpf_handle* h, const void*, int32_t, double, int32_t*, int32_t*) { return fail(h, RBPF_ESTATE, "not built yet"); }
+int rbpf_apply_resample_local(rbpf_handle* h, const int32_t*, const int32_t*) { return fail(h, RBPF_ESTATE, "not built yet"); }
+int64_t rbpf_packed_particle_bytes(rbpf_handle*) { return -1; }
+int rbpf_pack_particles(rbpf_handle* h, const int32_t*, int32_t, void*) { return fail(h, RBPF_ESTATE, "not built yet"); }
+int rbpf_unpack_particles(rbpf_handle* h, const int32_t*, int32_t, const void*) { return fail(h, RBPF_ESTATE, "not built yet"); }
+
+// ---- state access -----------------------------------------------------------------------------------------
+int rbpf_get_poses(rbpf_handle* h, double* out) {
+    if (!h || !out) return RBPF_EINVAL;
+    const size_t P = h->v.P;
+    std::vector<double> t(3 * P);
+    HIP_TRY(h, hipMemcpyAsync(t.data(), h->v.px, P * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(t.data() + P, h->v.py, P * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(t.data() + 2 * P, h->v.pth, P * 8, hipMemcpyDeviceToHost, h->stream));
+    int rc = check_device_error(h);
+    for (size_t p = 0; p < P; ++p) { out[3 * p] = t[p]; out[3 * p + 1] = t[P + p]; out[3 * p + 2] = t[2 * P + p]; }
+    return rc;
+}
+
+int rbpf_get_covs(rbpf_handle* h, double* out) {
+    if (!h || !out) return RBPF_EINVAL;
+    const size_t P = h->v.P;
+    std::vector<double> t(9 * P);
+    HIP_TRY(h, hipMemcpyAsync(t.data(), h->v.cov, 9 * P * 8, hipMemcpyDeviceToHost, h->stream));
+    int rc = check_device_error(h);
+    for (size_t p = 0; p < P; ++p) for (int k = 0; k < 9; ++k) out[9 * p + k] = t[(size_t)k * P + p];
+    return rc;
+}
+
+int rbpf_get_weights(rbpf_handle* h, double* out) {
+    if (!h || !out) return RBPF_EINVAL;
+    HIP_TRY(h, hipMemcpyAsync(out, h->v.weight, (size_t)h->v.P * 8, hipMemcpyDeviceToHost, h->stream));
+    return check_device_error(h);
+}
+
+int rbpf_set_state(rbpf_handle* h, const double* poses, const double* covs, const double* weights) {
+    if (!h) return RBPF_EINVAL;
+    const size_t P = h->v.P;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (poses) {
+        std::vector<double> t(3 * P);
+        for (size_t p = 0; p < P; ++p) { t[p] = poses[3 * p]; t[P + p] = poses[3 * p + 1]; t[2 * P + p] = poses[3 * p + 2]; }
+        HIP_TRY(h, hipMemcpy(h->v.px, t.data(), P * 8, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->v.py, t.data() + P, P * 8, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->v.pth, t.data() + 2 * P, P * 8, hipMemcpyHostToDevice));
+    }
+    if (covs) {
+        std::vector<double> t(9 * P);
+        for (size_t p = 0; p < P; ++p) for (int k = 0; k < 9; ++k) t[(size_t)k * P + p] = covs[9 * p + k];
+        HIP_TRY(h, hipMemcpy(h->v.cov, t.data(), 9 * P * 8, hipMemcpyHostToDevice));
+    }
+    if (weights) HIP_TRY(h, hipMemcpy(h->v.weight, weights, P * 8, hipMemcpyHostToDevice));
+    return RBPF_OK;
+}
+
+int rbpf_get_dim(rbpf_handle* h, int32_t* out) {
+    if (!h || !out) return RBPF_EINVAL;
+    *out = h->v.dim;
+    return RBPF_OK;
+}
+
+static int fetch_tab(rbpf_handle* h, int32_t particle, std::vector<int32_t>& tab) {
+    if (particle < 0 || particle >= h->v.P) return fail(h, RBPF_EINVAL, "particle index out of range");
+    const size_t LL = (size_t)h->v.L * h->v.L;
+    int32_t slot = 0;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(&slot, h->v.slot + particle, 4, hipMemcpyDeviceToHost));
+    tab.resize(LL);
+    HIP_TRY(h, hipMemcpy(tab.data(), h->v.tile_tab + (size_t)slot * LL, LL * 4, hipMemcpyDeviceToHost));
+    return RBPF_OK;
+}
+
+int rbpf_get_tile_count(rbpf_handle* h, int32_t particle, int32_t* out_n) {
+    if (!h || !out_n) return RBPF_EINVAL;
+    std::vector<int32_t> tab;
+    int rc = fetch_tab(h, particle, tab);
+    if (rc) return rc;
+    int n = 0;
+    for (int32_t t : tab) n += t >= 0;
+    *out_n = n;
+    return RBPF_OK;
+}
+
+int rbpf_get_tile(rbpf_handle* h, int32_t particle, int32_t k, double* centre2, int8_t* cells) {
+    if (!h || !centre2 || !cells) return RBPF_EINVAL;
+    std::vector<int32_t> tab;
+    int rc = fetch_tab(h, particle, tab);
+    if (rc) return rc;
+    const DevView& v = h->v;
+    int n = 0;
+    for (int a = 0; a < v.L; ++a)
+        for (int b = 0; b < v.L; ++b) {
+            int32_t t = tab[(size_t)a * v.L + b];
+            if (t < 0) continue;
+            if (n++ == k) {
+                centre2[0] = (double)(a - v.R) * v.tile_len;
+                centre2[1] = (double)(b - v.R) * v.tile_len;
+                HIP_TRY(h, hipMemcpy(cells, v.pool + (size_t)t * v.dim * v.dim, (size_t)v.dim * v.dim, hipMemcpyDeviceToHost));
+                return RBPF_OK;
+            }
+        }
+    return fail(h, RBPF_EINVAL, "tile index out of range");
+}
+
+int rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const int8_t* cells) {
+    if (!h || !cells) return RBPF_EINVAL;
+    std::vector<int32_t> tab;
+    int rc = fetch_tab(h, particle, tab);
+    if (rc) return rc;
+    DevView& v = h->v;
+    double fa = cx / v.tile_len, fb = cy / v.tile_len;
+    int a = (int)lround(fa), b = (int)lround(fb);
+    if (fabs(fa - a) > 1e-9 || fabs(fb - b) > 1e-9 || abs(a) > v.R || abs(b) > v.R)
+        return fail(h, RBPF_EINVAL, "tile centre must lie on the tile lattice inside lattice_radius");
+    const size_t LL = (size_t)v.L * v.L, idx = (size_t)(a + v.R) * v.L + (b + v.R);
+    int32_t t = tab[idx];
+    if (t < 0) {   // pop a tile from the free stack on the host side
+        int32_t top = 0;
+        HIP_TRY(h, hipMemcpy(&top, v.free_top, 4, hipMemcpyDeviceToHost));
+        if (top <= 0) return fail(h, RBPF_ENOMEM, "tile pool exhausted");
+        --top;
+        HIP_TRY(h, hipMemcpy(&t, v.free_stack + top, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(v.free_top, &top, 4, hipMemcpyHostToDevice));
+        int32_t slot = 0;
+        HIP_TRY(h, hipMemcpy(&slot, v.slot + particle, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(v.tile_tab + (size_t)slot * LL + idx, &t, 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(h, hipMemcpy(v.pool + (size_t)t * v.dim * v.dim, cells, (size_t)v.dim * v.dim, hipMemcpyHostToDevice));
+    int32_t bb[4] = {0, v.dim - 1, 0, v.dim - 1};       // unknown content: the whole tile counts as written
+    HIP_TRY(h, hipMemcpy(v.tile_bbox + 4 * (size_t)t, bb, sizeof(bb), hipMemcpyHostToDevice));
+    return RBPF_OK;
+}
+
+int rbpf_get_odds_at(rbpf_handle* h, int32_t particle, const double* xy, int32_t n, double* out_vals, uint8_t* out_none) {
+    if (!h || !xy || !out_vals || !out_none || n < 0) return RBPF_EINVAL;
+    if (particle < 0 || particle >= h->v.P) return fail(h, RBPF_EINVAL, "particle index out of range");
+    if (n == 0) return RBPF_OK;
+    double *d_xy = nullptr, *d_v = nullptr; uint8_t* d_n = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_xy, (size_t)n * 16));
+    HIP_TRY(h, hipMalloc((void**)&d_v, (size_t)n * 8));
+    HIP_TRY(h, hipMalloc((void**)&d_n, (size_t)n));
+    hipMemcpyAsync(d_xy, xy, (size_t)n * 16, hipMemcpyHostToDevice, h->stream);
+    launch_get_odds(h->v, particle, d_xy, n, d_v, d_n, h->stream);
+    hipMemcpyAsync(out_vals, d_v, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(out_none, d_n, (size_t)n, hipMemcpyDeviceToHost, h->stream);
+    int rc = check_device_error(h);
+    hipFree(d_xy); hipFree(d_v); hipFree(d_n);
+    return rc;
+}
+
+}  // extern "C"

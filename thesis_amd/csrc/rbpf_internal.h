@@ -1,0 +1,94 @@
+// rbpf_internal.h -- handle layout and kernel-launch prototypes of librbpf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rbpf_hip.h"
+#include "rbpf_math.h"
+
+namespace rbpf {
+
+static const int BLOCK = 256;          // 4 waves of 64
+static const int WIN = 128;            // LDS window edge (storage cells)
+static const int EV_CAP = 6;           // ordered events kept per flagged cell before the slow path
+static const int MAX_ITEMS_PER_PARTICLE = 64;
+
+// beam range classes, computed on the host from the float64 distance (rbpf_set_scan)
+enum { BF_WEIGHT = 1, BF_MATCH = 2, BF_LONG = 4 };
+
+// Everything a kernel needs, passed by value.
+struct DevView {
+    // configuration
+    int P, K, B, dim, R, L;            // L = 2R+1 lattice edge
+    int pool_tiles;
+    int items_cap;                     // window work items per particle (capacity)
+    int reach;                         // longest ray in cells (+ margin)
+    double cs, tile_len;
+    double quantum, inv_quantum;       // inv_quantum = round(1/quantum) when exact, else 0
+    CellConsts cc;
+    double w_min_range, w_max_range;
+    // LUT over global cell indices g in [g_min, g_min + n_lut)
+    const uint32_t* lut; int g_min, n_lut;
+    // particle state, SoA, logical particle order
+    double *px, *py, *pth;             // [P]
+    double *cov;                       // [9][P]
+    double *weight;                    // [P]
+    int32_t* slot;                     // [P] logical particle -> map slot
+    int32_t* global_id;                // [P] id of the particle in the multi-GPU job
+    // maps
+    int32_t* tile_tab;                 // [P slots][L*L] pool tile id or -1
+    int8_t*  pool;                     // [pool_tiles][dim*dim], cell[x*dim + y]
+    int32_t* tile_bbox;                // [pool_tiles][4] x_min, x_max, y_min, y_max (inclusive)
+    int32_t* free_stack;               // [pool_tiles]
+    int32_t* free_top;                 // [1] number of free tiles on the stack
+    // scan (sensor frame)
+    const double *bx, *by, *bscale;    // [B]
+    const uint8_t* bflags;             // [B]
+    // per-update scratch
+    double*  upd_pose;                 // [3][P] poses used by the current map update
+    int32_t* ray_end;                  // [P][B] packed (dx & 0xFFFF) | (dy << 16) relative to the start cell
+    int32_t* ray_start;                // [P][2] start cell, or INT_MIN when the particle is skipped
+    int32_t* items;                    // [P*MAX_ITEMS][4] particle, pool tile, wx0 | wy0<<16, lat x | lat y<<16
+    int32_t* n_items;                  // [1]
+    unsigned long long* stats;         // [8] device counters
+    int32_t* err;                      // [1] sticky device error code
+};
+
+enum { ST_RAY_CELLS = 0, ST_CELLS_WRITTEN = 1, ST_GATHERS = 2, ST_SLOW_CELLS = 3,
+       ST_COPIES = 4, ST_COPY_BYTES = 5 };
+
+}  // namespace rbpf
+
+struct rbpf_handle {
+    rbpf_config cfg;
+    rbpf::DevView v;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    bool have_scan = false;
+    std::string err;
+    std::vector<uint32_t> h_lut;
+    std::vector<void*> allocs;
+    // host staging
+    void* h_pinned = nullptr; size_t h_pinned_bytes = 0;
+    // scratch device buffers for test entries
+    double* d_guess = nullptr; double* d_prs = nullptr; double* d_w = nullptr; size_t d_guess_n = 0;
+    hipEvent_t ev[8];
+    rbpf_counters counters;
+    unsigned long long scan_updates = 0;
+};
+
+namespace rbpf {
+// kernel launchers (one translation unit per kernel family)
+void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
+                           double* d_out_w, hipStream_t s);
+void launch_map_update(const DevView& v, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
+                     uint8_t* d_none, hipStream_t s);
+void launch_imu_update(const DevView& v, int model, double d0, double d1, double d2, double dt_ticks,
+                       const double* vel_noise, hipStream_t s);
+size_t raycast_lds_bytes(int B);
+int raycast_items_cap(const rbpf_config& cfg);
+}  // namespace rbpf

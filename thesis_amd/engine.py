@@ -1,0 +1,197 @@
+"""ParticleEngine -- the batched structure-of-arrays engine behind Robot / HybridMap / resample.
+
+One ParticleEngine owns P particles on one MI355X: poses, covariances, weights and one tiled
+int8 occupancy map per particle, all resident in HBM.  Every method is one call into
+librbpf_hip.so (include/rbpf_hip.h); numpy arrays cross the boundary as plain pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import RbpfConfig, RbpfCounters, IMU_UNICYCLE, IMU_ABSOLUTE, IMU_VELOCITY
+
+IMU_MODEL_IDS = {"unicycle": IMU_UNICYCLE, "absolute": IMU_ABSOLUTE, "velocity": IMU_VELOCITY}
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class RbpfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"librbpf_hip error {code}: {msg}")
+        self.code = code
+
+
+class ParticleEngine:
+    """P particles, their maps and the per-scan update on one GPU."""
+
+    def __init__(self, n_particles: int, *, n_samples: int = 30, max_beams: int = 1081,
+                 cell_size: float = 0.05, tile_len_m: int = 40, lattice_radius: int = 3,
+                 pool_tiles: int = 0, device: int = 0, seed: int = 42, **overrides):
+        self._lib = _lib.load()
+        cfg = RbpfConfig()
+        self._check(self._lib.rbpf_default_config(C.byref(cfg)), None)
+        cfg.n_particles, cfg.n_samples, cfg.max_beams = n_particles, n_samples, max_beams
+        cfg.cell_size, cfg.tile_len_m, cfg.lattice_radius = cell_size, tile_len_m, lattice_radius
+        cfg.pool_tiles, cfg.device, cfg.seed = pool_tiles, device, seed
+        for k, v in overrides.items():
+            if k == "vel_noise":
+                for i in range(4):
+                    cfg.vel_noise[i] = v[i]
+            else:
+                if not hasattr(cfg, k):
+                    raise TypeError(f"unknown engine option {k!r}")
+                setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = self._lib.rbpf_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise RbpfError(rc, (self._lib.rbpf_last_error(None) or b"").decode())
+        self.P, self.K = n_particles, n_samples
+        d = C.c_int32()
+        self._check(self._lib.rbpf_get_dim(self._h, C.byref(d)))
+        self.dim = d.value
+        self.n_beams = 0
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def _check(self, rc: int, h="self"):
+        if rc != 0:
+            hh = self._h if h == "self" else None
+            raise RbpfError(rc, (self._lib.rbpf_last_error(hh) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.rbpf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        self._check(self._lib.rbpf_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self._lib.rbpf_synchronize(self._h))
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.rbpf_set_profiling(self._h, int(on)))
+
+    def counters(self) -> Dict[str, float]:
+        c = RbpfCounters()
+        self._check(self._lib.rbpf_get_counters(self._h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in RbpfCounters._fields_ if k != "reserved"}
+
+    # -- a1 ------------------------------------------------------------------------------------------
+    def set_scan(self, ranges, angles):
+        r, a = _f64(ranges), _f64(angles)
+        if r.shape != a.shape or r.ndim != 1:
+            raise ValueError("ranges and angles must be 1-D arrays of equal length")
+        self._check(self._lib.rbpf_set_scan(self._h, _dp(r), _dp(a), len(r)))
+        self.n_beams = len(r)
+
+    # -- a2 ------------------------------------------------------------------------------------------
+    def imu_update(self, model, data, dt_ticks: float):
+        mid = IMU_MODEL_IDS[model] if isinstance(model, str) else int(model)
+        d = np.zeros(3)
+        d[:len(data)] = np.asarray(data, dtype=np.float64)[:3]
+        self._check(self._lib.rbpf_imu_update(self._h, mid, _dp(d), float(dt_ticks)))
+
+    # -- a4 ------------------------------------------------------------------------------------------
+    def weight_samples(self, guesses, motion_prs) -> np.ndarray:
+        g = _f64(guesses)
+        K = g.shape[-2]
+        g = g.reshape(self.P, K, 3)
+        m = _f64(motion_prs).reshape(self.P, K)
+        out = np.empty((self.P, K), dtype=np.float64)
+        self._check(self._lib.rbpf_weight_samples(self._h, _dp(g), _dp(m), K, _dp(out)))
+        return out
+
+    # -- a5 ------------------------------------------------------------------------------------------
+    def map_update(self, poses=None):
+        if poses is None:
+            self._check(self._lib.rbpf_map_update(self._h, None))
+        else:
+            p = _f64(poses).reshape(self.P, 3)
+            self._check(self._lib.rbpf_map_update(self._h, _dp(p)))
+
+    # -- full step -----------------------------------------------------------------------------------
+    def scan_update(self, adj: bool = False, last_scan_xy=None, match_override=None, guesses=None):
+        ls = None if last_scan_xy is None else _f64(last_scan_xy).reshape(-1, 2)
+        mo = None if match_override is None else _f64(match_override).reshape(self.P, 13)
+        gs = None if guesses is None else _f64(guesses).reshape(self.P, self.K, 3)
+        self._check(self._lib.rbpf_scan_update(
+            self._h, int(adj), None if ls is None else _dp(ls), 0 if ls is None else len(ls),
+            None if mo is None else _dp(mo), None if gs is None else _dp(gs)))
+
+    def resample(self, u: float = float("nan")) -> Tuple[bool, np.ndarray]:
+        idx = np.empty(self.P, dtype=np.int32)
+        did = C.c_int32()
+        self._check(self._lib.rbpf_resample(self._h, float(u), _ip(idx), C.byref(did)))
+        return bool(did.value), idx
+
+    # -- state ---------------------------------------------------------------------------------------
+    def poses(self) -> np.ndarray:
+        out = np.empty((self.P, 3))
+        self._check(self._lib.rbpf_get_poses(self._h, _dp(out)))
+        return out
+
+    def covs(self) -> np.ndarray:
+        out = np.empty((self.P, 3, 3))
+        self._check(self._lib.rbpf_get_covs(self._h, _dp(out)))
+        return out
+
+    def weights(self) -> np.ndarray:
+        out = np.empty(self.P)
+        self._check(self._lib.rbpf_get_weights(self._h, _dp(out)))
+        return out
+
+    def set_state(self, poses=None, covs=None, weights=None):
+        p = None if poses is None else _f64(np.broadcast_to(poses, (self.P, 3)))
+        c = None if covs is None else _f64(np.broadcast_to(covs, (self.P, 3, 3)))
+        w = None if weights is None else _f64(np.broadcast_to(weights, (self.P,)))
+        self._check(self._lib.rbpf_set_state(self._h, None if p is None else _dp(p),
+                                             None if c is None else _dp(c), None if w is None else _dp(w)))
+
+    def tiles(self, particle: int) -> List[Tuple[Tuple[float, float], np.ndarray]]:
+        """[(centre_xy, cells int8 [dim, dim] indexed [x][y])] of one particle, lattice order."""
+        n = C.c_int32()
+        self._check(self._lib.rbpf_get_tile_count(self._h, particle, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            c = np.empty(2)
+            cells = np.empty((self.dim, self.dim), dtype=np.int8)
+            self._check(self._lib.rbpf_get_tile(self._h, particle, k, _dp(c), cells.ctypes.data_as(C.POINTER(C.c_int8))))
+            out.append(((float(c[0]), float(c[1])), cells))
+        return out
+
+    def set_tile(self, particle: int, centre, cells: np.ndarray):
+        cells = np.ascontiguousarray(cells, dtype=np.int8)
+        if cells.shape != (self.dim, self.dim):
+            raise ValueError("tile must be [dim, dim] int8")
+        self._check(self._lib.rbpf_set_tile(self._h, particle, float(centre[0]), float(centre[1]),
+                                            cells.ctypes.data_as(C.POINTER(C.c_int8))))
+
+    def get_odds_at(self, particle: int, xy) -> Tuple[np.ndarray, np.ndarray]:
+        pts = _f64(xy).reshape(-1, 2)
+        vals = np.empty(len(pts))
+        none = np.empty(len(pts), dtype=np.uint8)
+        self._check(self._lib.rbpf_get_odds_at(self._h, particle, _dp(pts), len(pts), _dp(vals),
+                                               none.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return vals, none.astype(bool)
