@@ -1,0 +1,252 @@
+// kernels_propose.hip -- a3 + a4: the body of Robot.map_update (robot.py:73-114) for all particles,
+// fused into one kernel per scan step:
+//
+//   proposal   K samples ~ N(scan_pose, scan_cov)        robot.py:81  (explicit samples or Philox)
+//              motion_pr = mvn.pdf(sample) * 10          robot.py:87  (scipy: eigen pseudo-inverse)
+//   weighting  w_k = (1 + sum of log-odds) * motion_pr   robot.py:118-139 (as kernels_weight.hip)
+//   moments    shifted weights, weighted mean / covariance, weight increment   robot.py:89-114
+//
+// One 256-thread workgroup per particle; the K sample poses live in LDS, the per-sample lattice sums
+// are exact integers, the moments are a K-term sequential float64 loop in the reference's order.
+// A particle whose matcher covariance holds a NaN takes the reference's fallback (robot.py:73-78):
+// its pose is kept, its map is updated at that pose and its weight is incremented AFTER the map
+// update by bad_weight_kernel.
+#include "rbpf_internal.h"
+#include "rbpf_device.h"
+
+namespace rbpf {
+
+static const int KMAX = 32;
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ void philox4x32(uint32_t ctr[4], uint64_t seed) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(ctr, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+}
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b) {   // (0,1], 53 bits
+    uint64_t m = ((uint64_t)a << 21) ^ (uint64_t)b >> 11;
+    return ((double)(m & ((1ull << 53) - 1)) + 1.0) * (1.0 / 9007199254740992.0);
+}
+// three standard normals for (seed, stream, p, k)
+__device__ void normals3(uint64_t seed, uint32_t stream, uint32_t p, uint32_t k, double z[3]) {
+    uint32_t c0[4] = {p, k, stream, 0u}, c1[4] = {p, k, stream, 1u};
+    philox4x32(c0, seed); philox4x32(c1, seed);
+    const double TWO_PI = 6.283185307179586;
+    double r0 = sqrt(-2.0 * log(u01(c0[0], c0[1]))), a0 = TWO_PI * u01(c0[2], c0[3]);
+    double r1 = sqrt(-2.0 * log(u01(c1[0], c1[1]))), a1 = TWO_PI * u01(c1[2], c1[3]);
+    z[0] = r0 * cos(a0); z[1] = r0 * sin(a0); z[2] = r1 * cos(a1);
+}
+
+// ---- symmetric 3x3 eigen-decomposition (cyclic Jacobi) ------------------------------------------------
+__device__ void eig3_sym(const double A[9], double w[3], double V[3][3]) {
+    double a[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { a[i][j] = 0.5 * (A[3 * i + j] + A[3 * j + i]); V[i][j] = i == j; }
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off <= 1e-300 || off <= 1e-20 * diag) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(a[p][q]) <= 1e-300) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {            // A <- A J
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {            // A <- J^T A
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = a[i][i];
+}
+
+struct ProposeArgs {
+    const double* match;        // [P][13] scan_pose(3), scan_cov(9), score
+    const double* guesses;      // [P][K][3] explicit samples, or nullptr
+    uint8_t* bad;               // [P] 1 = NaN covariance (robot.py:73)
+    uint64_t seed; uint32_t stream;
+    double* dbg_w;              // optional [P][K] raw sample weights (tests), or nullptr
+};
+
+__global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
+    __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
+    __shared__ int s_sum[KMAX];
+    __shared__ int s_tab[49];
+    __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
+    __shared__ int s_bad;
+    const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
+    const int LL = v.L * v.L;
+    const double* m = a.match + (size_t)p * 13;
+
+    if (tid == 0) {
+        bool bad = false;
+        for (int i = 0; i < 9; ++i) bad |= isnan(m[3 + i]);            // robot.py:73
+        s_bad = bad;
+        a.bad[p] = bad ? 1 : 0;
+        if (!bad) {
+            double w[3], V[3][3];
+            eig3_sym(m + 3, w, V);
+            // scipy.stats._multivariate._PSD: eps = 1e6 * eps_f64 * max|eig|; pseudo-inverse, pseudo-determinant
+            double mx = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
+            double eps = 1e6 * 2.220446049250313e-16 * mx;
+            double log_pdet = 0.0; int rank = 0;
+            for (int j = 0; j < 3; ++j) {
+                bool keep = w[j] > eps;
+                double inv_sqrt = fabs(w[j]) > eps ? sqrt(1.0 / w[j]) : 0.0;
+                if (keep) { log_pdet += log(w[j]); ++rank; }
+                double sq = w[j] > 0 ? sqrt(w[j]) : 0.0;
+                for (int i = 0; i < 3; ++i) { s_U[i][j] = V[i][j] * inv_sqrt; s_A[i][j] = V[i][j] * sq; }
+            }
+            s_logc = -0.5 * ((double)rank * 1.8378770664093453 + log_pdet);   // log(2*pi)
+            s_mean[0] = m[0]; s_mean[1] = m[1]; s_mean[2] = m[2];
+        }
+    }
+    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+    for (int i = tid; i < LL; i += BLOCK) s_tab[i] = tab[i];
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) { v.upd_pose[p] = v.px[p]; v.upd_pose[v.P + p] = v.py[p]; v.upd_pose[2 * v.P + p] = v.pth[p]; }
+        return;
+    }
+    if (tid < K) {
+        double g[3];
+        if (a.guesses) {
+            const double* gp = a.guesses + ((size_t)p * K + tid) * 3;
+            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+        } else {
+            double z[3];
+            normals3(a.seed, a.stream, (uint32_t)v.global_id[p], (uint32_t)tid, z);
+            for (int i = 0; i < 3; ++i) g[i] = s_mean[i] + ((s_A[i][0] * z[0] + s_A[i][1] * z[1]) + s_A[i][2] * z[2]);
+        }
+        // robot.py:87: pdf = exp(-0.5 * (rank*log(2pi) + log_pdet + maha)) * 10
+        double d0 = g[0] - s_mean[0], d1 = g[1] - s_mean[1], d2 = g[2] - s_mean[2];
+        double maha = 0.0;
+        for (int j = 0; j < 3; ++j) { double t = (d0 * s_U[0][j] + d1 * s_U[1][j]) + d2 * s_U[2][j]; maha += t * t; }
+        s_pr[tid] = exp(s_logc - 0.5 * maha) * 10;
+        double sn, cs;
+        sincos(g[2], &sn, &cs);
+        s_c[tid] = cs; s_s[tid] = sn; s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
+        s_sum[tid] = 0;
+    }
+    __syncthreads();
+
+    // ---- weighting: K gathers per beam, samples in chunks of 8 to bound register pressure --------------
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        int acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0;
+        for (int b = tid; b < v.B; b += BLOCK) {
+            if (!(v.bflags[b] & BF_WEIGHT)) continue;                 // robot.py:130
+            const double x = v.bx[b], y = v.by[b];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k0 + k < K) {
+                    double gx = (s_c[k0 + k] * x + (-s_s[k0 + k]) * y) + s_g[k0 + k][0];   // lidar.py:123
+                    double gy = (s_s[k0 + k] * x + s_c[k0 + k] * y) + s_g[k0 + k][1];
+                    int val;
+                    if (lookup_cell(v, s_tab, gx, gy, val)) acc[k] += val;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k0 + k < K) {
+                int s = acc[k];
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+                if ((tid & 63) == 0) atomicAdd(&s_sum[k0 + k], s);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < K) {
+        double obs = v.inv_quantum > 0 ? (v.inv_quantum + (double)s_sum[tid]) / v.inv_quantum
+                                       : 1.0 + (double)s_sum[tid] * v.quantum;
+        s_w[tid] = obs * s_pr[tid];                                   // robot.py:138
+        if (a.dbg_w) a.dbg_w[(size_t)p * K + tid] = s_w[tid];
+    }
+    __syncthreads();
+
+    // ---- moments, sequential in the reference's order (robot.py:89-114) --------------------------------
+    if (tid == 0) {
+        double min_w = s_w[0];
+        for (int k = 1; k < K; ++k) min_w = fmin(min_w, s_w[k]);
+        double mean[3] = {0, 0, 0}, norm = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double kw = (s_w[k] - min_w) + 1e-2;
+            s_w[k] = kw;
+            for (int i = 0; i < 3; ++i) mean[i] = mean[i] + s_g[k][i] * kw;
+            norm = norm + kw;
+        }
+        for (int i = 0; i < 3; ++i) mean[i] = mean[i] / norm;
+        double sig[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int k = 0; k < K; ++k) {
+            double d[3] = {s_g[k][0] + (-mean[0]), s_g[k][1] + (-mean[1]), s_g[k][2] + (-mean[2])};
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) sig[i][j] = sig[i][j] + (d[i] * d[j]) * s_w[k];
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) v.cov[(size_t)(3 * i + j) * v.P + p] = sig[i][j] / norm;   // robot.py:107,110
+        norm = norm + min_w * (double)K;                               // robot.py:108
+        v.px[p] = mean[0]; v.py[p] = mean[1]; v.pth[p] = mean[2];      // robot.py:111-113
+        v.weight[p] = norm + v.weight[p];                              // robot.py:114
+        v.upd_pose[p] = mean[0]; v.upd_pose[v.P + p] = mean[1]; v.upd_pose[2 * v.P + p] = mean[2];   // robot.py:115
+    }
+}
+
+// robot.py:75-77 for particles on the NaN branch: weight += (1 + sum log-odds at the latest pose) * 1,
+// evaluated on the map AFTER its update.
+__global__ __launch_bounds__(BLOCK) void bad_weight_kernel(DevView v, const uint8_t* __restrict__ bad) {
+    __shared__ int s_sum;
+    __shared__ int s_tab[49];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (!bad[p]) return;
+    const int LL = v.L * v.L;
+    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+    for (int i = tid; i < LL; i += BLOCK) s_tab[i] = tab[i];
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    double sn, cs;
+    sincos(v.pth[p], &sn, &cs);
+    const double tx = v.px[p], ty = v.py[p];
+    int acc = 0;
+    for (int b = tid; b < v.B; b += BLOCK) {
+        if (!(v.bflags[b] & BF_WEIGHT)) continue;
+        const double x = v.bx[b], y = v.by[b];
+        double gx = (cs * x + (-sn) * y) + tx, gy = (sn * x + cs * y) + ty;
+        int val;
+        if (lookup_cell(v, s_tab, gx, gy, val)) acc += val;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) atomicAdd(&s_sum, acc);
+    __syncthreads();
+    if (tid == 0) {
+        double obs = v.inv_quantum > 0 ? (v.inv_quantum + (double)s_sum) / v.inv_quantum : 1.0 + (double)s_sum * v.quantum;
+        v.weight[p] = obs * 1.0 + v.weight[p];
+    }
+}
+
+void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,
+                           uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s) {
+    ProposeArgs a{d_match, d_guesses, d_bad, seed, stream, d_dbg_w};
+    hipLaunchKernelGGL(propose_weight_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, a);
+}
+void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s) {
+    hipLaunchKernelGGL(bad_weight_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, d_bad);
+}
+
+}  // namespace rbpf

@@ -25,29 +25,9 @@
 #include <limits.h>
 
 #include "rbpf_internal.h"
+#include "rbpf_device.h"
 
 namespace rbpf {
-
-// ---- LUT helpers ------------------------------------------------------------------------------
-__device__ __forceinline__ bool lut_valid_g(const DevView& v, int g) {
-    return g >= v.g_min && g < v.g_min + v.n_lut;
-}
-__device__ __forceinline__ uint32_t lut_at(const DevView& v, int g) { return v.lut[g - v.g_min]; }
-
-// first global index whose packed entry is >= key (entries are non-decreasing in g)
-__device__ int lut_lower_bound(const DevView& v, uint32_t key) {
-    int lo = 0, hi = v.n_lut;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (v.lut[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return v.g_min + lo;
-}
-
-__device__ __forceinline__ void unpack_end(int32_t e, int x0, int y0, int& x1, int& y1) {
-    x1 = x0 + (int)(int16_t)(e & 0xFFFF);
-    y1 = y0 + (int)(int16_t)((uint32_t)e >> 16);
-}
 
 // =================================================================================================
 // ray_setup_kernel
@@ -519,7 +499,7 @@ int raycast_items_cap(const rbpf_config& cfg) {
 
 void launch_map_update(const DevView& v, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     // queue head lives right behind n_items
-    hipMemsetAsync(v.n_items, 0, 2 * sizeof(int32_t), s);
+    (void)hipMemsetAsync(v.n_items, 0, 2 * sizeof(int32_t), s);
     hipLaunchKernelGGL(ray_setup_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, v.items_cap);
     size_t lds = raycast_lds_bytes(v.B);
     int blocks_per_cu = (int)(160 * 1024 / (lds + 256));
@@ -528,13 +508,13 @@ void launch_map_update(const DevView& v, hipStream_t s, hipEvent_t e0, hipEvent_
     int grid = 256 * blocks_per_cu;
     static size_t lds_attr = 0;
     if (lds > lds_attr) {   // more than the default 64 KiB of dynamic LDS
-        hipFuncSetAttribute(reinterpret_cast<const void*>(raycast_window_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(raycast_window_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    if (e0) hipEventRecord(e0, s);
+    if (e0) (void)hipEventRecord(e0, s);
     hipLaunchKernelGGL(raycast_window_kernel, dim3(grid), dim3(BLOCK), lds, s, v, v.n_items + 1);
-    if (e1) hipEventRecord(e1, s);
+    if (e1) (void)hipEventRecord(e1, s);
 }
 
 }  // namespace rbpf

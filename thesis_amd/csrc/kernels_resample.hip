@@ -1,0 +1,335 @@
+// kernels_resample.hip -- a8 + a9: resample (main.py:46-79) and Robot.copy (robot.py:141-149).
+//
+// The reference draws ONE uniform and walks the particles once with a sequential longdouble
+// running sum (main.py:61-64).  Here the running sums are a parallel prefix scan in double-double
+// arithmetic (about 106 significant bits), i.e. closer to the exact sums than the reference's 64-bit
+// mantissa, so the integer ancestor indices agree unless a quotient lies within ~1e-14 of an integer.
+//   T_i   = floor((cum_i - start) / slice) + 1          survivors up to and including particle i
+//   idx_j = first i with T_i > j                        ancestor of new particle j
+// Particles keep their map "slot"; only duplicated ancestors cost a tile copy (as in the reference,
+// main.py:70-74), into the slot of a particle that died, restricted to the bounding boxes of the
+// cells ever written.
+#include <limits.h>
+
+#include "rbpf_internal.h"
+
+namespace rbpf {
+
+static const int PLAN_THREADS = 1024;
+
+__device__ __forceinline__ dd dd_two_prod(double a, double b) {
+    double p = a * b;
+    double e = __fma_rn(a, b, -p);          // exact error of the product (explicit FMA)
+    return {p, e};
+}
+__device__ __forceinline__ dd dd_mul_d(dd a, double b) {
+    dd p = dd_two_prod(a.hi, b);
+    double lo = p.lo + a.lo * b;
+    double hi = p.hi + lo;
+    return {hi, lo - (hi - p.hi)};
+}
+__device__ __forceinline__ dd dd_sub(dd a, dd b) { return dd_add(a, dd{-b.hi, -b.lo}); }
+__device__ __forceinline__ dd dd_div_d(dd a, double b) {
+    double q1 = a.hi / b;
+    dd r = dd_sub(a, dd_two_prod(q1, b));
+    double q2 = (r.hi + r.lo) / b;
+    double hi = q1 + q2;
+    return {hi, q2 - (hi - q1)};
+}
+// floor(a / b) for a, b double-double, b > 0
+__device__ long long dd_floor_div(dd a, dd b) {
+    double q0 = floor(a.hi / b.hi);
+    if (!(fabs(q0) < 9.0e15)) return q0 > 0 ? LLONG_MAX / 2 : LLONG_MIN / 2;
+    for (int it = 0; it < 4; ++it) {
+        dd r = dd_sub(a, dd_mul_d(b, q0));              // a - q0*b
+        if (r.hi < 0 || (r.hi == 0 && r.lo < 0)) { q0 -= 1.0; continue; }
+        dd r2 = dd_sub(r, b);
+        if (r2.hi > 0 || (r2.hi == 0 && r2.lo >= 0)) { q0 += 1.0; continue; }
+        break;
+    }
+    return (long long)q0;
+}
+
+struct ResampleArgs {
+    int P;
+    const double* w;          // [P] weights (global vector in the multi-GPU case)
+    double u;                 // uniform in [0,1)
+    double spread;            // main.py:50
+    int32_t* T;               // [P] survivors up to and including i
+    int32_t* did;             // [1]
+    int32_t* err;
+};
+
+// ---- kernel 1: trigger test, weight shift, double-double prefix sums, T array --------------------------
+__global__ __launch_bounds__(PLAN_THREADS) void resample_plan_kernel(ResampleArgs a) {
+    __shared__ double s_red[PLAN_THREADS];
+    __shared__ double s_hi[PLAN_THREADS], s_lo[PLAN_THREADS];
+    __shared__ double s_max, s_min, s_min2;
+    const int tid = threadIdx.x, nt = PLAN_THREADS;
+    const int chunk = (a.P + nt - 1) / nt;
+    const int i0 = min(tid * chunk, a.P), i1 = min(i0 + chunk, a.P);
+
+    // main.py:50  max(weights) - min(weights) > 200
+    double mx = -INFINITY, mn = INFINITY;
+    for (int i = i0; i < i1; ++i) { double w = a.w[i]; mx = fmax(mx, w); mn = fmin(mn, w); }
+    s_red[tid] = mx; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
+    if (tid == 0) s_max = s_red[0];
+    __syncthreads();
+    s_red[tid] = mn; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmin(s_red[tid], s_red[tid + s]); __syncthreads(); }
+    if (tid == 0) s_min = s_red[0];
+    __syncthreads();
+    const bool go = (s_max - s_min) > a.spread;
+    if (!go) {
+        for (int i = i0; i < i1; ++i) a.T[i] = i + 1;           // identity
+        if (tid == 0) *a.did = 0;
+        return;
+    }
+    // main.py:53-55: -inf -> 0, then every non-zero weight += |min| when the minimum is negative
+    double mn2 = INFINITY;
+    for (int i = i0; i < i1; ++i) { double w = a.w[i]; if (w == -INFINITY) w = 0.0; mn2 = fmin(mn2, w); }
+    s_red[tid] = mn2; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmin(s_red[tid], s_red[tid + s]); __syncthreads(); }
+    if (tid == 0) s_min2 = s_red[0];
+    __syncthreads();
+    const double shift = s_min2 < 0 ? fabs(s_min2) : 0.0;
+    auto adj = [&](double w) -> dd {
+        if (w == -INFINITY) return dd{0.0, 0.0};
+        if (shift != 0.0 && w != 0.0) return dd_two_sum(w, shift);
+        return dd{w, 0.0};
+    };
+
+    // chunk totals, then an inclusive Hillis-Steele scan over the 1024 totals
+    dd tot = {0.0, 0.0};
+    for (int i = i0; i < i1; ++i) tot = dd_add(tot, adj(a.w[i]));
+    s_hi[tid] = tot.hi; s_lo[tid] = tot.lo;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        dd v = {s_hi[tid], s_lo[tid]};
+        if (tid >= off) v = dd_add(dd{s_hi[tid - off], s_lo[tid - off]}, v);
+        __syncthreads();
+        s_hi[tid] = v.hi; s_lo[tid] = v.lo;
+        __syncthreads();
+    }
+    const dd total = {s_hi[nt - 1], s_lo[nt - 1]};
+    dd run = tid > 0 ? dd{s_hi[tid - 1], s_lo[tid - 1]} : dd{0.0, 0.0};
+    const dd slice = dd_div_d(total, (double)a.P);            // main.py:57
+    const dd start = dd_mul_d(slice, a.u);                    // main.py:59
+    bool bad = !(slice.hi > 0) || !isfinite(slice.hi);
+    for (int i = i0; i < i1; ++i) {
+        run = dd_add(run, adj(a.w[i]));                       // main.py:62
+        long long t = bad ? 0 : dd_floor_div(dd_sub(run, start), slice) + 1;   // main.py:63
+        if (t < 0) t = 0;
+        if (t > a.P) t = (long long)a.P + 1;
+        a.T[i] = (int32_t)t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *a.did = 1;
+        if (a.T[a.P - 1] != a.P) atomicCAS(a.err, 0, RBPF_ESTATE);   // main.py:66-67 AssertionError
+    }
+}
+
+// ---- kernel 2: ancestors by binary search over T -----------------------------------------------------
+__global__ void resample_expand_kernel(int P, const int32_t* __restrict__ T, int32_t* __restrict__ idx) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    int lo = 0, hi = P - 1;                                  // first i with T[i] > j
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (T[mid] > j) hi = mid; else lo = mid + 1;
+    }
+    idx[j] = lo;
+}
+
+// ---- kernel 3: pair duplicated ancestors with dead particles' map slots --------------------------------
+struct PairArgs {
+    int P;
+    const int32_t* T; const int32_t* idx; const int32_t* did;
+    const int32_t* slot_old; int32_t* slot_new;
+    int32_t* dead_list;       // [P] scratch
+    int32_t* jobs;            // [P][2] src slot, dst slot
+    int32_t* n_jobs;          // [1] (+ queue head behind it)
+};
+
+__device__ int block_exclusive_scan_1024(int val, int* s_buf, int tid, int& total) {
+    s_buf[tid] = val;
+    __syncthreads();
+    for (int off = 1; off < PLAN_THREADS; off <<= 1) {
+        int v = s_buf[tid];
+        if (tid >= off) v += s_buf[tid - off];
+        __syncthreads();
+        s_buf[tid] = v;
+        __syncthreads();
+    }
+    total = s_buf[PLAN_THREADS - 1];
+    return s_buf[tid] - val;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void resample_pair_kernel(PairArgs a) {
+    __shared__ int s_buf[PLAN_THREADS];
+    const int tid = threadIdx.x, nt = PLAN_THREADS;
+    const int chunk = (a.P + nt - 1) / nt;
+    const int i0 = min(tid * chunk, a.P), i1 = min(i0 + chunk, a.P);
+    if (!*a.did) {
+        for (int i = i0; i < i1; ++i) a.slot_new[i] = a.slot_old[i];
+        if (tid == 0) { a.n_jobs[0] = 0; a.n_jobs[1] = 0; }
+        return;
+    }
+    // dead particles (no survivor): cnt_i = T_i - T_{i-1} == 0
+    int n_dead = 0;
+    for (int i = i0; i < i1; ++i) n_dead += (a.T[i] - (i > 0 ? a.T[i - 1] : 0)) == 0;
+    int total_dead;
+    int base = block_exclusive_scan_1024(n_dead, s_buf, tid, total_dead);
+    for (int i = i0; i < i1; ++i)
+        if ((a.T[i] - (i > 0 ? a.T[i - 1] : 0)) == 0) a.dead_list[base++] = i;
+    __syncthreads();
+    // duplicates: new particle j whose ancestor equals that of j-1 (main.py:70-74)
+    int n_dup = 0;
+    for (int j = i0; j < i1; ++j) n_dup += (j > 0 && a.idx[j] == a.idx[j - 1]);
+    int total_dup;
+    int dbase = block_exclusive_scan_1024(n_dup, s_buf, tid, total_dup);
+    for (int j = i0; j < i1; ++j) {
+        int src = a.slot_old[a.idx[j]];
+        if (j > 0 && a.idx[j] == a.idx[j - 1]) {
+            int dst = a.slot_old[a.dead_list[dbase]];
+            a.jobs[2 * dbase] = src; a.jobs[2 * dbase + 1] = dst;
+            a.slot_new[j] = dst;
+            ++dbase;
+        } else {
+            a.slot_new[j] = src;
+        }
+    }
+    if (tid == 0) { a.n_jobs[0] = total_dup; a.n_jobs[1] = 0; }
+}
+
+// ---- kernel 4: permute the small per-particle state, weights <- 1.0 (main.py:77-78) ---------------------
+struct GatherArgs {
+    int P;
+    const int32_t* idx; const int32_t* did;
+    const double *px, *py, *pth, *cov, *w;
+    double *px2, *py2, *pth2, *cov2, *w2;
+};
+__global__ void resample_gather_kernel(GatherArgs a) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.P) return;
+    const int i = a.idx[j];
+    a.px2[j] = a.px[i]; a.py2[j] = a.py[i]; a.pth2[j] = a.pth[i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.cov2[(size_t)k * a.P + j] = a.cov[(size_t)k * a.P + i];
+    a.w2[j] = *a.did ? 1.0 : a.w[i];
+}
+
+// ---- kernel 5: tile copies -----------------------------------------------------------------------------
+struct CopyArgs {
+    DevView v;
+    const int32_t* jobs; int32_t* n_jobs;     // n_jobs[0] = jobs, n_jobs[1] = queue head
+    int32_t* pending_free; int32_t* n_pending;
+};
+
+__device__ __forceinline__ void copy_rows(int8_t* dst, const int8_t* src, int dim, int x0, int x1, int y0, int y1,
+                                          int tid) {
+    // rows x0..x1, columns rounded out to 16-byte groups; src == nullptr zero-fills
+    const int ya = y0 & ~15, yb = min((y1 | 15) + 1, dim);
+    const int per_row = (yb - ya) / 16;
+    const int n = (x1 - x0 + 1) * per_row;
+    for (int q = tid; q < n; q += BLOCK) {
+        int x = x0 + q / per_row, y = ya + (q % per_row) * 16;
+        size_t off = (size_t)x * dim + y;
+        uint4 val = src ? *reinterpret_cast<const uint4*>(src + off) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(dst + off) = val;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
+    __shared__ int s_item, s_tile;
+    const DevView& v = a.v;
+    const int tid = threadIdx.x;
+    const int LL = v.L * v.L;
+    const size_t cells = (size_t)v.dim * v.dim;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_item = atomicAdd(&a.n_jobs[1], 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= a.n_jobs[0] * LL) return;
+        const int job = item / LL, pos = item % LL;
+        const int src_slot = a.jobs[2 * job], dst_slot = a.jobs[2 * job + 1];
+        const int ts = v.tile_tab[(size_t)src_slot * LL + pos];
+        int td = v.tile_tab[(size_t)dst_slot * LL + pos];
+        if (ts < 0 && td < 0) continue;
+        if (ts >= 0) {
+            int sb[4], db[4] = {INT_MAX, -1, INT_MAX, -1};
+            for (int k = 0; k < 4; ++k) sb[k] = v.tile_bbox[4 * ts + k];
+            if (td < 0) {                                     // destination has no tile here: allocate
+                if (tid == 0) {
+                    int idx = atomicSub(v.free_top, 1) - 1;
+                    if (idx < 0) { atomicAdd(v.free_top, 1); atomicCAS(v.err, 0, RBPF_ENOMEM); s_tile = -1; }
+                    else { s_tile = v.free_stack[idx]; v.tile_tab[(size_t)dst_slot * LL + pos] = s_tile; }
+                }
+                __syncthreads();
+                td = s_tile;
+                if (td < 0) continue;
+            } else {
+                for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
+            }
+            // copy the union of both written regions (outside its box a tile is zero)
+            int x0 = min(sb[0], db[0]), x1 = max(sb[1], db[1]), y0 = min(sb[2], db[2]), y1 = max(sb[3], db[3]);
+            if (x0 <= x1 && y0 <= y1) {
+                copy_rows(v.pool + (size_t)td * cells, v.pool + (size_t)ts * cells, v.dim, x0, x1, y0, y1, tid);
+                if (tid == 0) {
+                    const int ya = y0 & ~15, yb = min((y1 | 15) + 1, v.dim);
+                    atomicAdd(&v.stats[ST_COPY_BYTES], 2ull * (unsigned long long)(x1 - x0 + 1) * (yb - ya));
+                }
+            }
+            if (tid == 0) {
+                for (int k = 0; k < 4; ++k) v.tile_bbox[4 * td + k] = sb[k];
+                atomicAdd(&v.stats[ST_COPIES], 1ull);
+            }
+        } else {                                              // source has no tile here: release the destination's
+            int db[4];
+            for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
+            if (db[0] <= db[1] && db[2] <= db[3])
+                copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+            if (tid == 0) {
+                v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1;
+                v.tile_bbox[4 * td + 2] = INT_MAX; v.tile_bbox[4 * td + 3] = -1;
+                v.tile_tab[(size_t)dst_slot * LL + pos] = -1;
+                a.pending_free[atomicAdd(a.n_pending, 1)] = td;   // pushed back after the kernel
+            }
+        }
+    }
+}
+
+__global__ void resample_release_kernel(DevView v, const int32_t* pending, int32_t* n_pending) {
+    // single thread block: return released tiles to the free stack (they are zero-filled)
+    const int n = *n_pending;
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = atomicAdd(v.free_top, n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v.free_stack[s_base + i] = pending[i];
+    __syncthreads();
+    if (threadIdx.x == 0) *n_pending = 0;
+}
+
+// ---- host-side launch sequence --------------------------------------------------------------------------
+void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
+                             int32_t* d_did, int32_t* d_err, hipStream_t s) {
+    ResampleArgs ra{P, d_w, u, spread, d_T, d_did, d_err};
+    hipLaunchKernelGGL(resample_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, ra);
+    hipLaunchKernelGGL(resample_expand_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, d_T, d_idx);
+}
+
+void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s) {
+    PairArgs pa{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs};
+    hipLaunchKernelGGL(resample_pair_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, pa);
+    GatherArgs ga{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight,
+                  b.px2, b.py2, b.pth2, b.cov2, b.w2};
+    hipLaunchKernelGGL(resample_gather_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, ga);
+    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
+    hipLaunchKernelGGL(resample_copy_kernel, dim3(1024), dim3(BLOCK), 0, s, ca);
+    hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
+}
+
+}  // namespace rbpf

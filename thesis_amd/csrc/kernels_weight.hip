@@ -7,25 +7,9 @@
 // exact int32; the only float work is the reference's float64 index expression
 // (gridmap.py:126) evaluated with its operation order.
 #include "rbpf_internal.h"
+#include "rbpf_device.h"
 
 namespace rbpf {
-
-// HybridMap.get_odds_at (hybridmap.py:85-93): value in quanta, or false for None.
-__device__ __forceinline__ bool lookup_cell(const DevView& v, const int32_t* __restrict__ tab,
-                                            double gx, double gy, int& val) {
-    int lx, ly;
-    if (!tile_of_coord(gx, v.tile_len, v.R, lx)) return false;   // hybridmap.py:44-45 is_in_map
-    if (!tile_of_coord(gy, v.tile_len, v.R, ly)) return false;
-    int t = tab[(lx + v.R) * v.L + (ly + v.R)];
-    if (t < 0) return false;
-    double rx = gx - (double)lx * v.tile_len;                    // hybridmap.py:88
-    double ry = gy - (double)ly * v.tile_len;
-    int ix, iy;
-    if (!get_cell_index(ry, v.tile_len, v.dim, iy)) return false; // gridmap.py:121-122
-    if (!get_cell_index(rx, v.tile_len, v.dim, ix)) return false; // gridmap.py:123-124
-    val = v.pool[(size_t)t * v.dim * v.dim + (size_t)ix * v.dim + iy];
-    return true;
-}
 
 static const int KMAX = 32;
 

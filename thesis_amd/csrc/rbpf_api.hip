@@ -104,7 +104,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     if (c.lattice_radius < 0 || c.lattice_radius > 3) return fail(nullptr, RBPF_EINVAL, "lattice_radius must be in 0..3");
     if (!(c.cell_size > 0) || c.tile_len_m < 1) return fail(nullptr, RBPF_EINVAL, "cell_size/tile_len_m");   // gridmap.py:29
     const int dim = (int)llround((double)c.tile_len_m / c.cell_size);                                        // gridmap.py:31
-    if (dim < WIN || dim > 4096 || dim % 4 != 0) return fail(nullptr, RBPF_EINVAL, "tile dimension must be a multiple of 4 in 128..4096 cells");
+    if (dim < WIN || dim > 4096 || dim % 16 != 0) return fail(nullptr, RBPF_EINVAL, "tile dimension must be a multiple of 16 in 128..4096 cells");
     if (!(c.max_ray_m > 0) || c.max_ray_m / c.cell_size + 4 >= dim)
         return fail(nullptr, RBPF_EINVAL, "max_ray_m must be shorter than one tile");
     CellConsts cc;
@@ -177,6 +177,14 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.ray_end, P * (size_t)c.max_beams); ALLOC(h, v.ray_start, 2 * P);
         ALLOC(h, v.items, P * (size_t)v.items_cap * 4); ALLOC(h, v.n_items, 2);
         ALLOC(h, v.stats, 8); ALLOC(h, v.err, 1);
+        ALLOC(h, h->d_match, 13 * P); ALLOC(h, h->d_bad, P); ALLOC(h, h->d_guess_full, P * (size_t)c.n_samples * 3);
+        {
+            ResampleBuffers& r = h->rs;
+            ALLOC(h, r.T, P); ALLOC(h, r.idx, P); ALLOC(h, r.did, 1); ALLOC(h, r.slot2, P); ALLOC(h, r.dead_list, P);
+            ALLOC(h, r.jobs, 2 * P); ALLOC(h, r.n_jobs, 2); ALLOC(h, r.pending_free, (size_t)v.pool_tiles); ALLOC(h, r.n_pending, 1);
+            ALLOC(h, r.px2, P); ALLOC(h, r.py2, P); ALLOC(h, r.pth2, P); ALLOC(h, r.cov2, 9 * P); ALLOC(h, r.w2, P);
+            HIP_TRY(h, hipMemset(r.n_pending, 0, 4)); HIP_TRY(h, hipMemset(r.n_jobs, 0, 8)); HIP_TRY(h, hipMemset(r.did, 0, 4));
+        }
         HIP_TRY(h, hipMemset(v.pool, 0, (size_t)v.pool_tiles * cells));
         HIP_TRY(h, hipMemset(v.px, 0, P * 8)); HIP_TRY(h, hipMemset(v.py, 0, P * 8)); HIP_TRY(h, hipMemset(v.pth, 0, P * 8));
         HIP_TRY(h, hipMemset(v.cov, 0, 9 * P * 8));
@@ -257,8 +265,11 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
     if (h->profiling) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) c.ms_raycast = ms;
-        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) c.ms_weight = ms;
+        if (h->ev_recorded[0] && hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) c.ms_raycast = ms;
+        if (h->ev_recorded[1] && hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) c.ms_weight = ms;
+        if (h->ev_recorded[2] && hipEventElapsedTime(&ms, h->ev[4], h->ev[5]) == hipSuccess) c.ms_resample = ms;
+        if (h->ev_recorded[3] && hipEventElapsedTime(&ms, h->ev[6], h->ev[7]) == hipSuccess) c.ms_match = ms;
+        (void)hipGetLastError();
     }
     *out = c;
     return RBPF_OK;
@@ -324,9 +335,9 @@ int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_guess, guesses, n * 3 * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_prs, prs, n * 8, hipMemcpyHostToDevice, h->stream));
-    if (h->profiling) hipEventRecord(h->ev[2], h->stream);
+    if (h->profiling) (void)hipEventRecord(h->ev[2], h->stream);
     launch_weight_samples(h->v, h->d_guess, h->d_prs, K, h->d_w, h->stream);
-    if (h->profiling) hipEventRecord(h->ev[3], h->stream);
+    if (h->profiling) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_recorded[1] = true; }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out_w, h->d_w, n * 8, hipMemcpyDeviceToHost, h->stream));
     return check_device_error(h);
@@ -340,6 +351,7 @@ static int run_map_update(rbpf_handle* h) {
     static bool attr_set = false;
     (void)attr_set;
     launch_map_update(v, h->stream, h->profiling ? h->ev[0] : nullptr, h->profiling ? h->ev[1] : nullptr);
+    if (h->profiling) h->ev_recorded[0] = true;
     HIP_TRY(h, hipGetLastError());
     h->scan_updates++;
     return RBPF_OK;
@@ -365,10 +377,38 @@ int rbpf_map_update(rbpf_handle* h, const double* poses) {
     return check_device_error(h);
 }
 
-// ---- not yet implemented in this build step (declared so that the ABI is complete) ----------------------
-int rbpf_scan_update(rbpf_handle* h, int32_t, const double*, int32_t, const double*, const double*) {
-    return fail(h, RBPF_ESTATE, "rbpf_scan_update: not built yet");
+static int run_matcher(rbpf_handle* h, int32_t, const double*, int32_t) {
+    return fail(h, RBPF_ESTATE, "built-in matcher: not built yet (pass match_override)");
 }
+
+// ---- Robot.map_update for every particle (robot.py:59-115) -------------------------------------------------
+int rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
+                     const double* match_override, const double* guesses) {
+    if (!h) return RBPF_EINVAL;
+    if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
+    DevView& v = h->v;
+    const size_t P = v.P;
+    if (match_override) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_match, match_override, 13 * P * 8, hipMemcpyHostToDevice, h->stream));
+    } else {
+        int rc = run_matcher(h, adj, last_scan_xy, n_last);
+        if (rc) return rc;
+    }
+    const double* d_g = nullptr;
+    if (guesses) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_guess_full, guesses, P * (size_t)v.K * 3 * 8, hipMemcpyHostToDevice, h->stream));
+        d_g = h->d_guess_full;
+    }
+    if (h->profiling) (void)hipEventRecord(h->ev[2], h->stream);
+    launch_propose_weight(v, h->d_match, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
+    if (h->profiling) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_recorded[1] = true; }
+    int rc = run_map_update(h);                 // HybridMap.update at the new mean pose (robot.py:115)
+    if (rc) return rc;
+    launch_bad_weight(v, h->d_bad, h->stream);  // robot.py:73-78 fallback, after the map update
+    HIP_TRY(h, hipGetLastError());
+    return RBPF_OK;
+}
+
 int rbpf_match_scan(rbpf_handle* h, const double*, int32_t, const double*, int32_t, const double*, int32_t,
                     const double*, double*, double*, double*) {
     return fail(h, RBPF_ESTATE, "rbpf_match_scan: not built yet");
@@ -376,7 +416,40 @@ int rbpf_match_scan(rbpf_handle* h, const double*, int32_t, const double*, int32
 int rbpf_match_inputs(rbpf_handle* h, int32_t, const double*, double*, int32_t*, double*, int32_t*, int32_t) {
     return fail(h, RBPF_ESTATE, "rbpf_match_inputs: not built yet");
 }
-int rbpf_resample(rbpf_handle* h, double, int32_t*, int32_t*) { return fail(h, RBPF_ESTATE, "rbpf_resample: not built yet"); }
+
+// ---- resample (main.py:46-79) -------------------------------------------------------------------------------
+static double internal_uniform(rbpf_handle* h) {
+    uint64_t z = h->cfg.seed + 0x9E3779B97F4A7C15ull * (++h->resample_draws);   // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+static void swap_state_buffers(rbpf_handle* h) {
+    DevView& v = h->v; ResampleBuffers& r = h->rs;
+    std::swap(v.px, r.px2); std::swap(v.py, r.py2); std::swap(v.pth, r.pth2);
+    std::swap(v.cov, r.cov2); std::swap(v.weight, r.w2); std::swap(v.slot, r.slot2);
+}
+
+int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resample) {
+    if (!h) return RBPF_EINVAL;
+    DevView& v = h->v;
+    if (u != u) u = internal_uniform(h);
+    if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
+    HIP_TRY(h, hipMemsetAsync(&v.stats[ST_COPIES], 0, 2 * sizeof(unsigned long long), h->stream));
+    if (h->profiling) (void)hipEventRecord(h->ev[4], h->stream);
+    launch_resample_indices(v.P, v.weight, u, h->cfg.resample_spread, h->rs.T, h->rs.idx, h->rs.did, v.err, h->stream);
+    launch_resample_apply(v, h->rs, h->stream);
+    if (h->profiling) { (void)hipEventRecord(h->ev[5], h->stream); h->ev_recorded[2] = true; }
+    HIP_TRY(h, hipGetLastError());
+    swap_state_buffers(h);
+    if (idx_out) HIP_TRY(h, hipMemcpyAsync(idx_out, h->rs.idx, (size_t)v.P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (did_resample) HIP_TRY(h, hipMemcpyAsync(did_resample, h->rs.did, 4, hipMemcpyDeviceToHost, h->stream));
+    if (idx_out || did_resample) return check_device_error(h);
+    return RBPF_OK;
+}
+
 int rbpf_export_weights(rbpf_handle* h, void*, int32_t) { return fail(h, RBPF_ESTATE, "not built yet"); }
 int rbpf_resample_indices_global(rbpf_handle* h, const void*, int32_t, double, int32_t*, int32_t*) { return fail(h, RBPF_ESTATE, "not built yet"); }
 int rbpf_apply_resample_local(rbpf_handle* h, const int32_t*, const int32_t*) { return fail(h, RBPF_ESTATE, "not built yet"); }

@@ -56,6 +56,15 @@ struct DevView {
     int32_t* err;                      // [1] sticky device error code
 };
 
+// double buffers and scratch of the resample step
+struct ResampleBuffers {
+    int32_t *T, *idx, *did;            // [P], [P], [1]
+    int32_t *slot2, *dead_list, *jobs; // [P], [P], [P][2]
+    int32_t *n_jobs;                   // [2] job count, queue head
+    int32_t *pending_free, *n_pending; // [pool_tiles], [1]
+    double *px2, *py2, *pth2, *cov2, *w2;
+};
+
 enum { ST_RAY_CELLS = 0, ST_CELLS_WRITTEN = 1, ST_GATHERS = 2, ST_SLOW_CELLS = 3,
        ST_COPIES = 4, ST_COPY_BYTES = 5 };
 
@@ -75,7 +84,11 @@ struct rbpf_handle {
     void* h_pinned = nullptr; size_t h_pinned_bytes = 0;
     // scratch device buffers for test entries
     double* d_guess = nullptr; double* d_prs = nullptr; double* d_w = nullptr; size_t d_guess_n = 0;
+    double* d_match = nullptr; uint8_t* d_bad = nullptr; double* d_guess_full = nullptr;
+    unsigned long long resample_draws = 0;
     hipEvent_t ev[8];
+    bool ev_recorded[4] = {false, false, false, false};
+    rbpf::ResampleBuffers rs;
     rbpf_counters counters;
     unsigned long long scan_updates = 0;
 };
@@ -89,6 +102,12 @@ void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, 
                      uint8_t* d_none, hipStream_t s);
 void launch_imu_update(const DevView& v, int model, double d0, double d1, double d2, double dt_ticks,
                        const double* vel_noise, hipStream_t s);
+void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
+                             int32_t* d_did, int32_t* d_err, hipStream_t s);
+void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s);
+void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,
+                           uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s);
+void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s);
 size_t raycast_lds_bytes(int B);
 int raycast_items_cap(const rbpf_config& cfg);
 }  // namespace rbpf
