@@ -12,6 +12,7 @@ Vector sets:
   G1 get_affected_points        G2 tile index formulas     G3 HybridMap.update
   G4 get_odds_at                G5 _generate_sample_weight G6 Robot.map_update
   G7 Robot.imu_update           G8 main.resample           G9 get_scan_match inputs
+  G10 debug.mat (data file: a captured matchScanCustom argument tuple)
 """
 import contextlib
 import io
@@ -432,11 +433,21 @@ def g8():
     save("G8_resample", **out)
 
 
+def g10():
+    """debug.mat: one captured argument tuple of matchScanCustom (inputs only, no outputs exist)."""
+    from scipy.io import loadmat
+    d = loadmat(os.path.join(REF, "debug.mat"))
+    save("G10_debug_mat_inputs", curr=d["curr"].astype(np.float64), ref=d["ref"].astype(np.float64),
+         guess=d["guess"].astype(np.float64).ravel(), resolution=np.array(int(d["resolution"].ravel()[0])),
+         rng=d["rng"].astype(np.float64).ravel())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g69", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g69", "g7", "g8", "g10"]
     if "g1" in which: g1()
     if "g2" in which: g2()
     if "g345" in which: g3_g4_g5()
     if "g69" in which: g6_g9()
     if "g7" in which: g7()
     if "g8" in which: g8()
+    if "g10" in which: g10()

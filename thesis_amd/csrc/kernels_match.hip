@@ -1,0 +1,392 @@
+// kernels_match.hip -- a6 + a7: the scan-match stage of Robot.map_update (robot.py:62-69), i.e.
+// HybridMap.get_scan_match / get_scan_adj (hybridmap.py:147-261) + matchScanCustom.m.
+//
+// PARITY UNPINNED.  The reference hands its point lists to MATLAB Navigation Toolbox R2021a
+// (matchScansGrid, then matchScans/NDT); that code is closed source, absent from the reference tree,
+// and no recorded outputs exist.  What is kept is the interface and the decision logic:
+//   inputs   the scan, the particle's own map (adj = 0) or the previous accepted scan (adj = 1),
+//            the odometry pose as initial guess, the search window of robot.py:62-65 with the
+//            rotation range hard-wired to pi/6 (hybridmap.py:249);
+//   outputs  pose = guess + offset (hybridmap.py:253-255), a 3x3 covariance, a score; a failed match
+//            is reported as NaN covariance / score 0 (matchScanCustom.m:25-28) and sends the particle
+//            down robot.py:73-78.
+// The numerics are this library's own two-level correlative matcher (Olson 2009 style):
+//   field    occupancy bits of the region around the guess (cells with log-odds > threshold,
+//            gridmap.py:153) plus their 3x3 dilation, staged in LDS;  hit = 2 on an occupied cell, 1 on a
+//            dilated one;
+//   coarse   4x4 max-pooled field, rotation step 4*d0, translation step 4 cells, every 8th beam;
+//   fine     around the coarse optimum: rotation step d0 = cell/max_range, translation step 1 cell,
+//            every 4th beam;
+//   cov      second moments of exp((s - s_best)/tau) over the fine candidates + a floor.
+// The NDT refinement (matchScanCustom.m:32-50) is not reproduced.
+#include <limits.h>
+#include <string.h>
+
+#include "rbpf_internal.h"
+#include "rbpf_device.h"
+
+namespace rbpf {
+
+static const int M_COARSE = 4;          // coarse cell = 4 fine cells
+static const int M_FINE_T = 4;          // fine translations: -4..4 cells around the coarse optimum
+static const int M_FINE_R = 4;          // fine rotations:   -4..4 steps of d0
+
+struct MatchArgs {
+    int mode;                   // 0: field from the particle's map; 1: field from ref points (last scan)
+    int single;                 // 1: stateless twin (one problem: explicit guess/range, curr points as beams)
+    const double* ref_xy; int n_ref;       // mode 1 points (global frame)
+    double guess[3]; double range[3];      // single = 1
+    double* out;                // [P][13] pose, cov, score
+    int N;                      // region edge in matcher cells (multiple of 32)
+    int ds;                     // matcher cell = ds map cells
+    double mcs;                 // matcher cell size in metres
+    double d0;                  // fine rotation step
+    double rot_range;           // pi/6 (hybridmap.py:249)
+    double max_range;           // beams/points farther than this are ignored (hybridmap.py:20)
+    const float* sel_x; const float* sel_y; int n_sel;   // selected beams / curr points, sensor frame, metres
+    int n_coarse_rot;           // rotations on each side at the coarse level
+    int cap_sel;                // LDS capacity for selected beams
+    double cell_off;            // 0.5 in the stateless twin: its points are snapped to cell corners (hybridmap.py:226-227)
+};
+
+struct MatchLds {
+    uint32_t* occ;      // [N][N/32]
+    uint32_t* dil;      // [N][N/32]
+    uint32_t* crs;      // [N/4][words]
+    float* bx; float* by;   // [nb] selected beams in matcher-cell units
+    int* sc;            // [n coarse candidates] then reused for fine
+};
+
+__host__ __device__ inline int match_crs_words(int N) { return ((N / M_COARSE) + 31) / 32; }
+
+size_t match_lds_bytes(int N, int B, int n_coarse) {
+    size_t words = (size_t)N * (N / 32);
+    int fine = (2 * M_FINE_R + 1) * (2 * M_FINE_T + 1) * (2 * M_FINE_T + 1);
+    size_t nsc = (size_t)(n_coarse > fine ? n_coarse : fine);
+    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + (size_t)B * 8 + nsc * 4 + 128;
+}
+
+__device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w) {
+    if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0;
+    int idx = u * (N >> 5) + (w >> 5);
+    uint32_t m = 1u << (w & 31);
+    return ((s.occ[idx] & m) ? 1 : 0) + ((s.dil[idx] & m) ? 1 : 0);
+}
+__device__ __forceinline__ int coarse_hit(const MatchLds& s, int N, int u, int w) {
+    if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0;
+    int cu = u / M_COARSE, cw = w / M_COARSE;
+    return (s.crs[cu * match_crs_words(N) + (cw >> 5)] >> (cw & 31)) & 1u;
+}
+
+__global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, W = N >> 5, tid = threadIdx.x, p = blockIdx.x;
+    MatchLds s;
+    s.occ = reinterpret_cast<uint32_t*>(smem);
+    s.dil = s.occ + (size_t)N * W;
+    s.crs = s.dil + (size_t)N * W;
+    s.bx = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N));
+    s.by = s.bx + a.cap_sel;
+    s.sc = reinterpret_cast<int*>(s.by + a.cap_sel);
+    __shared__ double s_g[3], s_rng[2];
+    __shared__ int s_org[2], s_nb, s_best, s_bestc;
+    __shared__ double s_mom[10];
+    __shared__ int s_tab[49];
+
+    // ---- guess, search window (robot.py:62-65), region origin ----------------------------------------------
+    if (tid == 0) {
+        double gx, gy, gth, rx, ry;
+        if (a.single) {
+            gx = a.guess[0]; gy = a.guess[1]; gth = a.guess[2]; rx = a.range[0]; ry = a.range[1];
+        } else {
+            gx = v.px[p]; gy = v.py[p]; gth = v.pth[p];
+            double c00 = v.cov[(size_t)0 * v.P + p], c11 = v.cov[(size_t)4 * v.P + p];
+            double p0 = sqrt(c00) * 30.0, p1 = sqrt(c11) * 30.0;                 // robot.py:62
+            ry = fmax(fmin(4 * p1, 0.7), 0.1);                                   // robot.py:64
+            rx = fmax(fmin(4 * p0, 0.7), 0.1);                                   // robot.py:65
+        }
+        s_g[0] = gx; s_g[1] = gy; s_g[2] = gth; s_rng[0] = rx; s_rng[1] = ry;
+        s_org[0] = (int)floor(gx / a.mcs) - N / 2;
+        s_org[1] = (int)floor(gy / a.mcs) - N / 2;
+        s_nb = 0; s_best = INT_MIN; s_bestc = 0;
+        for (int i = 0; i < 10; ++i) s_mom[i] = 0.0;
+    }
+    if (!a.single) {
+        const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * v.L * v.L;
+        for (int i = tid; i < v.L * v.L; i += BLOCK) s_tab[i] = tab[i];
+    }
+    for (int i = tid; i < N * W; i += BLOCK) { s.occ[i] = 0; s.dil[i] = 0; }
+    for (int i = tid; i < (N / M_COARSE) * match_crs_words(N); i += BLOCK) s.crs[i] = 0;
+    __syncthreads();
+    const int ox = s_org[0], oy = s_org[1];
+
+    // ---- field ------------------------------------------------------------------------------------------------
+    if (a.mode == 0) {
+        // occupancy of the particle's own map over the region (cells > threshold, gridmap.py:153)
+        const size_t cells = (size_t)v.dim * v.dim;
+        for (int q = tid; q < N * W; q += BLOCK) {
+            const int u = q / W, wv = q % W;
+            uint32_t bits = 0;
+            for (int du = 0; du < a.ds; ++du) {
+                const int gxi = (ox + u) * a.ds + du;
+                if (!lut_valid_g(v, gxi)) continue;
+                const uint32_t ex = lut_at(v, gxi);
+                for (int b = 0; b < 32 * a.ds; ++b) {
+                    const int gyi = (oy + wv * 32) * a.ds + b;
+                    if (!lut_valid_g(v, gyi)) continue;
+                    const uint32_t ey = lut_at(v, gyi);
+                    const int t = s_tab[lut_lat(ex) * v.L + lut_lat(ey)];
+                    if (t < 0) continue;
+                    int val = v.pool[(size_t)t * cells + (size_t)lut_cidx(ex) * v.dim + lut_cidx(ey)];
+                    if (val > v.cc.thr) bits |= 1u << (b / a.ds);
+                }
+            }
+            s.occ[q] = bits;
+        }
+    } else {
+        // occupancy rasterised from reference points (previous accepted scan, hybridmap.py:167-171)
+        for (int i = tid; i < a.n_ref; i += BLOCK) {
+            double rx = a.ref_xy[2 * i], ry = a.ref_xy[2 * i + 1];
+            double dx = rx - s_g[0], dy = ry - s_g[1];
+            if (!(sqrt(dx * dx + dy * dy) < a.max_range)) continue;   // hybridmap.py:171 (11 m); matchScanCustom.m:11 (15 m)
+            int u = (int)floor(rx / a.mcs + a.cell_off) - ox, w = (int)floor(ry / a.mcs + a.cell_off) - oy;
+            if ((unsigned)u < (unsigned)N && (unsigned)w < (unsigned)N) atomicOr(&s.occ[u * W + (w >> 5)], 1u << (w & 31));
+        }
+    }
+    // selected beams (in matcher-cell units, sensor frame)
+    for (int b = tid; b < a.n_sel; b += BLOCK) { s.bx[b] = (float)((double)a.sel_x[b] / a.mcs); s.by[b] = (float)((double)a.sel_y[b] / a.mcs); }
+    if (tid == 0) s_nb = a.n_sel;
+    __syncthreads();
+    // 3x3 dilation and 4x4 max-pool of the dilated field
+    for (int q = tid; q < N * W; q += BLOCK) {
+        const int u = q / W, wv = q % W;
+        uint32_t acc = 0;
+        for (int du = -1; du <= 1; ++du) {
+            int uu = u + du;
+            if (uu < 0 || uu >= N) continue;
+            uint32_t c = s.occ[uu * W + wv];
+            uint32_t l = wv > 0 ? s.occ[uu * W + wv - 1] : 0, r = wv + 1 < W ? s.occ[uu * W + wv + 1] : 0;
+            acc |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+        }
+        s.dil[q] = acc;
+    }
+    __syncthreads();
+    for (int q = tid; q < N * W; q += BLOCK) {
+        uint32_t d = s.dil[q];
+        if (!d) continue;
+        const int u = q / W, wv = q % W;
+        for (int k = 0; k < 32 / M_COARSE; ++k)
+            if ((d >> (k * M_COARSE)) & 0xFu) {
+                int cw = (wv * 32) / M_COARSE + k, cu = u / M_COARSE;
+                atomicOr(&s.crs[cu * match_crs_words(N) + (cw >> 5)], 1u << (cw & 31));
+            }
+    }
+    __syncthreads();
+
+    const int nb = s_nb;
+    const float fx = (float)(s_g[0] / a.mcs - (double)ox + a.cell_off), fy = (float)(s_g[1] / a.mcs - (double)oy + a.cell_off);
+    const double gth = s_g[2];
+    // translation half-widths in matcher cells; candidates must satisfy |d| < range (matchScanCustom.m:53)
+    const double rxc = s_rng[0] / a.mcs, ryc = s_rng[1] / a.mcs;
+    const int ktx = (int)ceil(rxc / M_COARSE) - 1;    // largest k with k*M_COARSE < range
+    const int kty = (int)ceil(ryc / M_COARSE) - 1;
+    const int ntx = 2 * max(ktx, 0) + 1, nty = 2 * max(kty, 0) + 1;
+    const int nr = 2 * a.n_coarse_rot + 1;
+    const int n_coarse = nr * ntx * nty;
+
+    // ---- coarse level -------------------------------------------------------------------------------------------
+    for (int cnd = tid; cnd < n_coarse; cnd += BLOCK) {
+        const int ir = cnd / (ntx * nty), it = cnd % (ntx * nty);
+        double snd, csd;
+        sincos(gth + (double)(ir - a.n_coarse_rot) * M_COARSE * a.d0, &snd, &csd);
+        const float sn = (float)snd, cs = (float)csd;
+        const float tx = fx + (float)((it / nty - max(ktx, 0)) * M_COARSE), ty = fy + (float)((it % nty - max(kty, 0)) * M_COARSE);
+        int sc = 0;
+        for (int b = 0; b < nb; b += 8) {
+            float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
+            sc += coarse_hit(s, N, (int)floorf(ex), (int)floorf(ey));
+        }
+        s.sc[cnd] = sc;
+        atomicMax(&s_best, sc);
+    }
+    __syncthreads();
+    if (tid == 0) s_bestc = INT_MAX;
+    __syncthreads();
+    const int best_coarse = s_best;
+    for (int cnd = tid; cnd < n_coarse; cnd += BLOCK) {
+        if (s.sc[cnd] == best_coarse) {
+            // ties: the candidate closest to the guess, then the lowest index (deterministic)
+            const int ir = cnd / (ntx * nty), it = cnd % (ntx * nty);
+            int dr = ir - a.n_coarse_rot, dx = it / nty - max(ktx, 0), dy = it % nty - max(kty, 0);
+            int key = ((dr * dr + dx * dx + dy * dy) << 16) | cnd;
+            atomicMin(&s_bestc, key);
+        }
+    }
+    __syncthreads();
+    const int cbest = s_bestc & 0xFFFF;
+    const int cir = cbest / (ntx * nty) - a.n_coarse_rot, cit = cbest % (ntx * nty);
+    const int ctx = (cit / nty - max(ktx, 0)) * M_COARSE, cty = (cit % nty - max(kty, 0)) * M_COARSE;
+    __syncthreads();
+    if (tid == 0) s_best = INT_MIN;
+    __syncthreads();
+
+    // ---- fine level -----------------------------------------------------------------------------------------------
+    const int FR = 2 * M_FINE_R + 1, FT = 2 * M_FINE_T + 1;
+    const int n_fine = FR * FT * FT;
+    for (int cnd = tid; cnd < n_fine; cnd += BLOCK) {
+        const int ir = cnd / (FT * FT) - M_FINE_R, ix = (cnd / FT) % FT - M_FINE_T, iy = cnd % FT - M_FINE_T;
+        const double dth = (double)(cir * M_COARSE + ir) * a.d0;
+        const int dx = ctx + ix, dy = cty + iy;
+        int sc = -1;                                   // -1: outside the search window
+        if (fabs(dth) < a.rot_range && fabs((double)dx) < rxc && fabs((double)dy) < ryc) {
+            double snd, csd;
+            sincos(gth + dth, &snd, &csd);
+            const float sn = (float)snd, cs = (float)csd;
+            const float tx = fx + (float)dx, ty = fy + (float)dy;
+            sc = 0;
+            for (int b = 0; b < nb; b += 4) {
+                float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
+                sc += field_hit(s, N, (int)floorf(ex), (int)floorf(ey));
+            }
+        }
+        s.sc[cnd] = sc;
+        atomicMax(&s_best, sc);
+    }
+    __syncthreads();
+    if (tid == 0) s_bestc = INT_MAX;
+    __syncthreads();
+    const int best = s_best;
+    for (int cnd = tid; cnd < n_fine; cnd += BLOCK) {
+        if (s.sc[cnd] == best) {
+            const int ir = cnd / (FT * FT) - M_FINE_R, ix = (cnd / FT) % FT - M_FINE_T, iy = cnd % FT - M_FINE_T;
+            int dr = cir * M_COARSE + ir, dx = ctx + ix, dy = cty + iy;
+            int key = (min(dr * dr + dx * dx + dy * dy, 32767) << 16) | cnd;
+            atomicMin(&s_bestc, key);
+        }
+    }
+    __syncthreads();
+    const int fbest = s_bestc & 0xFFFF;
+    const double bth = (double)(cir * M_COARSE + (fbest / (FT * FT) - M_FINE_R)) * a.d0;
+    const double bdx = (double)(ctx + (fbest / FT) % FT - M_FINE_T) * a.mcs, bdy = (double)(cty + fbest % FT - M_FINE_T) * a.mcs;
+
+    // score of the selected pose over ALL beams (the search levels subsample them)
+    __syncthreads();
+    if (tid == 0) s_best = 0;
+    __syncthreads();
+    {
+        double snd, csd;
+        sincos(gth + bth, &snd, &csd);
+        const float sn = (float)snd, cs = (float)csd;
+        const float tx = fx + (float)(bdx / a.mcs), ty = fy + (float)(bdy / a.mcs);
+        int sc = 0;
+        for (int b = tid; b < nb; b += BLOCK) {
+            float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
+            sc += field_hit(s, N, (int)floorf(ex), (int)floorf(ey));
+        }
+        for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off, 64);
+        if ((tid & 63) == 0) atomicAdd(&s_best, sc);
+    }
+    __syncthreads();
+    const int full_score = s_best;
+
+    // ---- covariance: second moments of exp((s - s_best)/tau) over the fine candidates ----------------------------
+    {
+        const double tau = fmax(1.0, 0.02 * (double)((nb + 3) / 4) * 2.0);
+        double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int cnd = tid; cnd < n_fine; cnd += BLOCK) {
+            int sc = s.sc[cnd];
+            if (sc < 0) continue;
+            const int ir = cnd / (FT * FT) - M_FINE_R, ix = (cnd / FT) % FT - M_FINE_T, iy = cnd % FT - M_FINE_T;
+            double w = exp((double)(sc - best) / tau);
+            double ex = (double)(ctx + ix) * a.mcs - bdx, ey = (double)(cty + iy) * a.mcs - bdy;
+            double et = (double)(cir * M_COARSE + ir) * a.d0 - bth;
+            m[0] += w; m[1] += w * ex; m[2] += w * ey; m[3] += w * et;
+            m[4] += w * ex * ex; m[5] += w * ex * ey; m[6] += w * ex * et; m[7] += w * ey * ey; m[8] += w * ey * et; m[9] += w * et * et;
+        }
+        for (int k = 0; k < 10; ++k) {
+            double x = m[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((tid & 63) == 0) atomicAdd(&s_mom[k], x);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double* o = a.out + (size_t)p * 13;
+        const bool ok = best > 0 && nb > 0;                       // no overlap at all: matchScanCustom.m:25-28
+        o[0] = s_g[0] + bdx; o[1] = s_g[1] + bdy; o[2] = s_g[2] + bth;   // hybridmap.py:253-255
+        if (!ok) {
+            for (int k = 0; k < 9; ++k) o[3 + k] = NAN;
+            o[12] = 0.0;
+        } else {
+            const double sw = s_mom[0];
+            double mu[3] = {s_mom[1] / sw, s_mom[2] / sw, s_mom[3] / sw};
+            double c[3][3];
+            c[0][0] = s_mom[4] / sw - mu[0] * mu[0]; c[0][1] = s_mom[5] / sw - mu[0] * mu[1]; c[0][2] = s_mom[6] / sw - mu[0] * mu[2];
+            c[1][1] = s_mom[7] / sw - mu[1] * mu[1]; c[1][2] = s_mom[8] / sw - mu[1] * mu[2]; c[2][2] = s_mom[9] / sw - mu[2] * mu[2];
+            c[1][0] = c[0][1]; c[2][0] = c[0][2]; c[2][1] = c[1][2];
+            // floor: a quarter cell / a quarter rotation step of quantisation noise
+            const double fl_t = (a.mcs * a.mcs) / 16.0, fl_r = (a.d0 * a.d0) / 16.0;
+            c[0][0] = fmax(c[0][0], 0.0) + fl_t; c[1][1] = fmax(c[1][1], 0.0) + fl_t; c[2][2] = fmax(c[2][2], 0.0) + fl_r;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 + 3 * i + j] = c[i][j];
+            o[12] = 0.5 * (double)full_score;
+        }
+    }
+}
+
+// region edge in matcher cells and the matcher-cell scale for a configuration
+void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot) {
+    ds = 1;
+    for (;;) {
+        mcs = cell_size * ds;
+        int half = (int)ceil((c.match_max_range + 0.5 + 0.7) / mcs) + 2;
+        N = ((2 * half + 31) / 32) * 32;
+        // occupancy + dilation bitmasks must fit in LDS next to the beam list and the score table
+        if (2 * (size_t)N * (N / 32) * 4 <= 120 * 1024 || ds >= 8) break;
+        ds *= 2;
+    }
+    d0 = mcs / c.match_max_range;
+    const double rot = 3.141592653589793 / 6;
+    n_coarse_rot = (int)floor(rot / (M_COARSE * d0));
+    if (n_coarse_rot * M_COARSE * d0 >= rot) --n_coarse_rot;
+    if (n_coarse_rot < 0) n_coarse_rot = 0;
+}
+
+int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs) {
+    int k = (int)ceil(max_range_m / mcs / M_COARSE);
+    return (2 * n_coarse_rot + 1) * (2 * k + 1) * (2 * k + 1);
+}
+
+static void launch_match(const DevView& v, const MatchArgs& a, int grid, size_t lds, hipStream_t s) {
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(BLOCK), lds, s, v, a);
+}
+
+void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
+                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, hipStream_t s) {
+    MatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = mode; a.single = 0; a.ref_xy = d_ref; a.n_ref = n_ref; a.out = d_out;
+    a.N = N; a.ds = ds; a.mcs = mcs; a.d0 = d0; a.rot_range = 3.141592653589793 / 6; a.max_range = max_range;
+    a.sel_x = mode ? v.asel_x : v.msel_x; a.sel_y = mode ? v.asel_y : v.msel_y; a.n_sel = mode ? v.n_asel : v.n_msel;
+    a.n_coarse_rot = ncr; a.cap_sel = cap_sel;
+    launch_match(v, a, v.P, lds, s);
+}
+
+void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
+                         const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
+                         double d0, int ncr, int cap_sel, size_t lds, hipStream_t s) {
+    MatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = 1; a.single = 1; a.ref_xy = d_ref; a.n_ref = n_ref; a.out = d_out;
+    for (int i = 0; i < 3; ++i) { a.guess[i] = guess3[i]; a.range[i] = range3[i]; }
+    a.N = N; a.ds = ds; a.mcs = mcs; a.d0 = d0; a.rot_range = range3[2]; a.max_range = 15.0;
+    a.sel_x = d_sel_x; a.sel_y = d_sel_y; a.n_sel = n_sel; a.n_coarse_rot = ncr; a.cap_sel = cap_sel;
+    a.cell_off = 0.5;
+    launch_match(v, a, 1, lds, s);
+}
+
+}  // namespace rbpf

@@ -177,6 +177,12 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.ray_end, P * (size_t)c.max_beams); ALLOC(h, v.ray_start, 2 * P);
         ALLOC(h, v.items, P * (size_t)v.items_cap * 4); ALLOC(h, v.n_items, 2);
         ALLOC(h, v.stats, 8); ALLOC(h, v.err, 1);
+        ALLOC(h, v.msel_x, (size_t)c.max_beams); ALLOC(h, v.msel_y, (size_t)c.max_beams);
+        ALLOC(h, v.asel_x, (size_t)c.max_beams); ALLOC(h, v.asel_y, (size_t)c.max_beams);
+        ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
+        match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
+        h->mlds = match_lds_bytes(h->mN, c.max_beams, match_max_coarse(h->mncr, 0.7, h->mmcs));
+        if (h->mlds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this cell_size");
         ALLOC(h, h->d_match, 13 * P); ALLOC(h, h->d_bad, P); ALLOC(h, h->d_guess_full, P * (size_t)c.n_samples * 3);
         {
             ResampleBuffers& r = h->rs;
@@ -203,7 +209,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemcpy(v.free_stack, fs.data(), (size_t)v.pool_tiles * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(v.free_top, &top, 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(v.tile_bbox, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
-        h->h_pinned_bytes = std::max<size_t>((size_t)c.max_beams * 32, 1 << 16);
+        h->h_pinned_bytes = std::max<size_t>((size_t)c.max_beams * 64, 1 << 16);
         HIP_TRY(h, hipHostMalloc(&h->h_pinned, h->h_pinned_bytes, hipHostMallocDefault));
         // the ray-cast kernel needs more than the default 64 KiB of dynamic LDS
         return RBPF_OK;
@@ -292,11 +298,26 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
         uint8_t f = 0;
         if (dist < c.weight_max_range && dist > c.weight_min_range) f |= BF_WEIGHT;   // robot.py:130
         if (dist < c.match_max_range && dist > c.match_min_range) f |= BF_MATCH;      // hybridmap.py:218
+        if (dist < c.match_max_range) f |= BF_MATCH_ADJ;                              // hybridmap.py:172
         double s = 1.0;
         if (dist > c.max_ray_m) { f |= BF_LONG; s = c.max_ray_m / dist; }             // hybridmap.py:107-108
         sx[i] = x; sy[i] = y; sc[i] = s; fl[i] = f;
     }
     DevView& v = h->v;
+    {   // compacted beam lists for the matcher (float32, sensor frame)
+        float* mx = reinterpret_cast<float*>(fl + ((B + 15) & ~15));
+        float* my = mx + B; float* ax = my + B; float* ay = ax + B;
+        int nm = 0, na = 0;
+        for (int i = 0; i < B; ++i) {
+            if (fl[i] & BF_MATCH) { mx[nm] = (float)sx[i]; my[nm] = (float)sy[i]; ++nm; }
+            if (fl[i] & BF_MATCH_ADJ) { ax[na] = (float)sx[i]; ay[na] = (float)sy[i]; ++na; }
+        }
+        v.n_msel = nm; v.n_asel = na;
+        HIP_TRY(h, hipMemcpyAsync(v.msel_x, mx, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(v.msel_y, my, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(v.asel_x, ax, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(v.asel_y, ay, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.bx), sx, B * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.by), sy, B * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.bscale), sc, B * 8, hipMemcpyHostToDevice, h->stream));
@@ -377,8 +398,17 @@ int rbpf_map_update(rbpf_handle* h, const double* poses) {
     return check_device_error(h);
 }
 
-static int run_matcher(rbpf_handle* h, int32_t, const double*, int32_t) {
-    return fail(h, RBPF_ESTATE, "built-in matcher: not built yet (pass match_override)");
+static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last) {
+    DevView& v = h->v;
+    if (adj && (!last_scan_xy || n_last < 0 || n_last > h->cfg.max_beams))
+        return fail(h, RBPF_EINVAL, "adj = 1 needs last_scan_xy with at most max_beams points");
+    if (adj) HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, last_scan_xy, (size_t)n_last * 16, hipMemcpyHostToDevice, h->stream));
+    if (h->profiling) (void)hipEventRecord(h->ev[6], h->stream);
+    launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
+                           h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, h->stream);
+    if (h->profiling) { (void)hipEventRecord(h->ev[7], h->stream); h->ev_recorded[3] = true; }
+    HIP_TRY(h, hipGetLastError());
+    return RBPF_OK;
 }
 
 // ---- Robot.map_update for every particle (robot.py:59-115) -------------------------------------------------
@@ -409,9 +439,45 @@ int rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, in
     return RBPF_OK;
 }
 
-int rbpf_match_scan(rbpf_handle* h, const double*, int32_t, const double*, int32_t, const double*, int32_t,
-                    const double*, double*, double*, double*) {
-    return fail(h, RBPF_ESTATE, "rbpf_match_scan: not built yet");
+// matchScanCustom(curr, ref, guess, cells_per_m, pose_range) -> pose, cov, score  (hybridmap.py:244-251)
+int rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const double* ref_xy, int32_t n_ref,
+                    const double* guess3, int32_t cells_per_m, const double* pose_range3, double* pose_out3,
+                    double* cov_out9, double* score_out) {
+    if (!h || !curr_xy || !guess3 || !pose_range3 || !pose_out3 || !cov_out9 || !score_out) return RBPF_EINVAL;
+    if (n_curr < 0 || n_curr > h->cfg.max_beams || n_ref < 0 || (n_ref > 0 && !ref_xy)) return fail(h, RBPF_EINVAL, "point counts out of range");
+    if (cells_per_m < 1) return fail(h, RBPF_EINVAL, "cells_per_m must be >= 1");
+    rbpf_config c = h->cfg;
+    c.match_max_range = 15.0;                       // matchScanCustom.m:11 'MaxRange', 15
+    int N, ds, ncr; double mcs, d0;
+    match_geometry(c, 1.0 / (double)cells_per_m, N, ds, mcs, d0, ncr);
+    ncr = (int)floor(fabs(pose_range3[2]) / (4 * d0));             // coarse rotation step = 4 * d0
+    if (ncr * 4 * d0 >= fabs(pose_range3[2])) --ncr;
+    if (ncr < 0) ncr = 0;
+    size_t lds = match_lds_bytes(N, h->cfg.max_beams, match_max_coarse(ncr, std::max(pose_range3[0], pose_range3[1]), mcs));
+    if (lds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this resolution");
+    std::vector<float> sel(2 * (size_t)h->cfg.max_beams, 0.f);
+    for (int i = 0; i < n_curr; ++i) { sel[i] = (float)curr_xy[2 * i]; sel[h->cfg.max_beams + i] = (float)curr_xy[2 * i + 1]; }
+    double *d_ref = nullptr, *d_out = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_ref, std::max<size_t>((size_t)n_ref, 1) * 16));
+    HIP_TRY(h, hipMalloc((void**)&d_out, 13 * 8));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (n_ref) HIP_TRY(h, hipMemcpyAsync(d_ref, ref_xy, (size_t)n_ref * 16, hipMemcpyHostToDevice, h->stream));
+    launch_match_single(h->v, d_ref, n_ref, guess3, pose_range3, h->d_tmp_sel, h->d_tmp_sel + h->cfg.max_beams, n_curr, d_out,
+                        N, ds, mcs, d0, ncr, h->cfg.max_beams, lds, h->stream);
+    double out[13];
+    HIP_TRY(h, hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    int rc = check_device_error(h);
+    (void)hipFree(d_ref); (void)hipFree(d_out);
+    if (rc) return rc;
+    // matchScanCustom.m:19,52-57 validity gate
+    const double PI = 3.141592653589793;
+    double dth = fmod(out[2] - guess3[2] + PI, 2 * PI); if (dth < 0) dth += 2 * PI; dth -= PI;
+    bool valid = fabs(out[0] - guess3[0]) < fabs(pose_range3[0]) && fabs(out[1] - guess3[1]) < fabs(pose_range3[1]) &&
+                 fabs(dth) < fabs(pose_range3[2]) && !(out[3] != out[3]);
+    for (int i = 0; i < 3; ++i) pose_out3[i] = out[i];
+    for (int i = 0; i < 9; ++i) cov_out9[i] = valid ? out[3 + i] : std::numeric_limits<double>::quiet_NaN();
+    *score_out = valid ? out[12] : 0.0;
+    return RBPF_OK;
 }
 int rbpf_match_inputs(rbpf_handle* h, int32_t, const double*, double*, int32_t*, double*, int32_t*, int32_t) {
     return fail(h, RBPF_ESTATE, "rbpf_match_inputs: not built yet");

@@ -16,7 +16,7 @@ static const int EV_CAP = 6;           // ordered events kept per flagged cell b
 static const int MAX_ITEMS_PER_PARTICLE = 64;
 
 // beam range classes, computed on the host from the float64 distance (rbpf_set_scan)
-enum { BF_WEIGHT = 1, BF_MATCH = 2, BF_LONG = 4 };
+enum { BF_WEIGHT = 1, BF_MATCH = 2, BF_LONG = 4, BF_MATCH_ADJ = 8 };
 
 // Everything a kernel needs, passed by value.
 struct DevView {
@@ -46,6 +46,8 @@ struct DevView {
     // scan (sensor frame)
     const double *bx, *by, *bscale;    // [B]
     const uint8_t* bflags;             // [B]
+    float *msel_x, *msel_y; int n_msel;  // beams with BF_MATCH, compacted (metres, sensor frame)
+    float *asel_x, *asel_y; int n_asel;  // beams with BF_MATCH_ADJ, compacted
     // per-update scratch
     double*  upd_pose;                 // [3][P] poses used by the current map update
     int32_t* ray_end;                  // [P][B] packed (dx & 0xFFFF) | (dy << 16) relative to the start cell
@@ -84,6 +86,8 @@ struct rbpf_handle {
     void* h_pinned = nullptr; size_t h_pinned_bytes = 0;
     // scratch device buffers for test entries
     double* d_guess = nullptr; double* d_prs = nullptr; double* d_w = nullptr; size_t d_guess_n = 0;
+    int mN = 0, mds = 1, mncr = 0; double mmcs = 0, md0 = 0; size_t mlds = 0;
+    double* d_last_xy = nullptr; float* d_tmp_sel = nullptr;
     double* d_match = nullptr; uint8_t* d_bad = nullptr; double* d_guess_full = nullptr;
     unsigned long long resample_draws = 0;
     hipEvent_t ev[8];
@@ -108,6 +112,14 @@ void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream
 void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s);
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s);
+size_t match_lds_bytes(int N, int B, int n_coarse);
+void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot);
+int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs);
+void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
+                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, hipStream_t s);
+void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
+                         const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
+                         double d0, int ncr, int cap_sel, size_t lds, hipStream_t s);
 size_t raycast_lds_bytes(int B);
 int raycast_items_cap(const rbpf_config& cfg);
 }  // namespace rbpf

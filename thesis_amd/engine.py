@@ -195,3 +195,15 @@ class ParticleEngine:
         self._check(self._lib.rbpf_get_odds_at(self._h, particle, _dp(pts), len(pts), _dp(vals),
                                                none.ctypes.data_as(C.POINTER(C.c_uint8))))
         return vals, none.astype(bool)
+
+
+def match_scan(engine: ParticleEngine, curr_xy, ref_xy, guess, cells_per_m: int, pose_range):
+    """Stateless twin of the reference's engine seam ``matchScanCustom(curr, ref, guess, cells_per_m,
+    pose_range, nargout=3)`` (hybridmap.py:244-251): returns (pose[3], cov[3,3], score); a failed match
+    has NaN covariance and score 0 (matchScanCustom.m:25-28)."""
+    cu, rf = _f64(curr_xy).reshape(-1, 2), _f64(ref_xy).reshape(-1, 2)
+    g, pr = _f64(guess).reshape(3), _f64(pose_range).reshape(3)
+    pose, cov, score = np.empty(3), np.empty((3, 3)), C.c_double()
+    engine._check(engine._lib.rbpf_match_scan(engine._h, _dp(cu), len(cu), _dp(rf), len(rf), _dp(g), int(cells_per_m),
+                                              _dp(pr), _dp(pose), _dp(cov), C.byref(score)))
+    return pose, cov, score.value
