@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/s of the RBPF-SLAM particle-update hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one accepted lidar scan of the reference's main loop (main.py:138-214) over all particles:
+IMU propagation (robot.py:45-57), Robot.map_update for every particle (robot.py:59-115: scan match,
+30-sample proposal, weighting, moments, ray-cast map update) and resample (main.py:46-79), with the
+reference's scan-match cadence (main.py:156-159) and last_scan refresh (main.py:167-168).
+
+Workload (BASELINE.json configs[1]): 1024 particles per GPU, 1081 beams over 270
+degrees, 0.05 m cells, synthetic `room16` world (no 1081-beam Intel log exists).  Weak scaling: every rank
+holds 1024 particles; the per-particle weights are all-reduced over RCCL before the global resampling.
+Inputs (the scan log) are generated before the timed region; one scan (17 KB) is uploaded per step.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PERIOD_S = 0.7                 # one accepted scan every 0.35 m of travel (main.py:42 DIST_THRESHOLD = 0.33)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=1024, help="particles per GPU")
+    ap.add_argument("--beams", type=int, default=1081)
+    ap.add_argument("--cell-size", type=float, default=0.05)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target-run", action="store_true", help="skip the extra 10 240-particle measurement")
+    return ap.parse_args()
+
+
+class Runner:
+    """The reference's event loop body for accepted scans, on one rank."""
+
+    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None):
+        from thesis_amd.engine import ParticleEngine
+        self.P, self.B, self.rank, self.world = P, B, rank, world
+        self.angles, self.ranges, self.odo, self.true_poses = log
+        self.e = ParticleEngine(P, max_beams=B, cell_size=cell_size, pool_tiles=2 * P + 64, seed=42 + rank)
+        self.shard = shard
+        if shard is not None:
+            shard.attach(self.e)
+        self.frame = 0
+        self.last_scan_xy = None
+        self.urng = np.random.Generator(np.random.PCG64(777))   # same stream on every rank
+        # cold start: the first scan goes into every map at the origin (update_count < 2 branch, main.py:155)
+        self.e.set_scan(self.ranges[0], self.angles)
+        self.e.map_update(np.zeros((P, 3)))
+        self._refresh_last_scan(0, np.zeros(3))
+
+    def _refresh_last_scan(self, k, pose0):
+        # main.py:167-168: last_scan = scan.from_global_reference(particles[0].get_latest_pose())
+        r, a = self.ranges[k], self.angles
+        c, s = np.cos(pose0[2]), np.sin(pose0[2])
+        x, y = r * np.cos(a), r * np.sin(a)
+        self.last_scan_xy = np.stack([c * x - s * y + pose0[0], s * x + c * y + pose0[1]], axis=1)
+
+    def step(self):
+        k = self.frame
+        e = self.e
+        e.imu_update("velocity", self.odo[k], PERIOD_S * 1e4)                 # main.py:139-145
+        e.set_scan(self.ranges[k + 1], self.angles)
+        adj = not (k % 5 < 2)                                                 # main.py:156-159
+        e.scan_update(adj=adj, last_scan_xy=self.last_scan_xy if adj else None)
+        u = float(self.urng.random())
+        if self.shard is None:
+            e.resample_async(u)                                               # main.py:160
+        else:
+            self.shard.resample(u)
+        if k % 5 == 0:                                                        # main.py:167
+            pose0 = e.poses()[0] if self.shard is None else self.shard.pose_of_particle0()
+            self._refresh_last_scan(k + 1, pose0)
+        self.frame += 1
+
+
+def cpu_baseline(log, B, cell_size, seconds=12.0):
+    """Reference-equivalent CPU path (oracle/rbpf_oracle.c, pinned bit-exact to the reference's outputs):
+    Robot.map_update without the MATLAB scan matcher (as BASELINE.md section 2), all host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle, rbpf_oracle as orc
+    lib = c_oracle.load()
+    angles, ranges, odo, poses = log
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                 # a one-GPU box's CPU share
+    n_steps = 3
+    sx = np.empty((n_steps, B)); sy = np.empty((n_steps, B))
+    for s in range(n_steps):
+        sx[s], sy[s] = orc.scan_xy(ranges[s], angles)
+    rng = np.random.Generator(np.random.PCG64(5))
+    K = 30
+
+    def work(n_particles):
+        g = (poses[:n_steps, None, None, :] + rng.normal(0, 0.01, size=(n_steps, n_particles, K, 3))).copy()
+        prs = np.ones((n_steps, n_particles, K))
+        t0 = time.perf_counter()
+        lib.orc_bench_particle_updates(n_particles, n_steps, c_oracle.dp(sx), c_oracle.dp(sy), B, c_oracle.dp(g),
+                                       c_oracle.dp(prs), K, cell_size)
+        return time.perf_counter() - t0
+
+    t1 = work(4)                                   # calibrate: 4 particles x 3 steps on one core
+    per_pu = t1 / (4 * n_steps)
+    n_each = max(1, min(int(seconds / (per_pu * n_steps)), 2000))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:          # ctypes releases the GIL: real parallelism
+        list(ex.map(work, [n_each] * cores))
+    wall = time.perf_counter() - t0
+    total = cores * n_each * n_steps
+    return {"value": total / wall, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{total} particle-updates ({cores} threads x {n_each} particles x {n_steps} scans, B={B}, "
+                      f"cs={cell_size}): C restatement of Robot.map_update (weighting + moments + ray-cast), "
+                      f"scan matcher excluded (MATLAB, not timeable); single core: {1.0 / per_pu:.1f}/s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from thesis_amd.datasets import synthetic
+    n_scans = args.steps + args.warmup + 2
+    log = synthetic.make_log(n_scans, args.beams, period=PERIOD_S)
+
+    shard = None
+    if world > 1:
+        from thesis_amd.sharding import ShardedResampler
+        shard = ShardedResampler(rank, world, args.particles, device=local_rank)
+    os.environ.setdefault("RBPF_DEVICE", str(local_rank))
+    run = Runner(args.particles, args.beams, args.cell_size, log, rank, world, shard)
+    if world > 1:
+        run.e.close()
+        raise SystemExit("sharded path is wired in a later step")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.step()
+    run.e.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+
+    P_total = args.particles * world
+    value = P_total * args.steps / elapsed
+    # ---- roofline of the dominant kernel, HIP events recorded inside the timed region ------------------
+    kms = {k: run.e.kernel_ms(k) for k in ("raycast", "weight", "resample", "match", "ray_setup")}
+    mean_ms = {k: (float(v.mean()) if len(v) else 0.0) for k, v in kms.items()}
+    c = run.e.counters()
+    n_upd = max(1, args.steps)
+    W_per_particle = c["cells_written"] / (n_upd * args.particles)          # |W|, unique cells written per particle-update
+    cells_per_particle = c["ray_cells_visited"] / (n_upd * args.particles)
+    dominant = max(("raycast", "weight", "match", "resample"), key=lambda k: mean_ms[k])
+    # algorithmic bytes with 4-byte cells.  Per particle-update:
+    #   ray-cast kernel   4|W| read + 4|W| write
+    #   weighting kernel  4|R_w|, R_w = cells under the K*B sample endpoints (<= K*B, ~B distinct)
+    #   match kernel      4 * region cells (the occupancy region staged once per particle)
+    alg_bytes = {"raycast": 8.0 * W_per_particle, "weight": 4.0 * args.beams * 2,
+                 "match": 4.0 * 480 * 480, "resample": 0.0}
+    if c["resample_copies"]:
+        alg_bytes["resample"] = 4.0 * c["bytes_copied"] / (n_upd * args.particles)
+    ach = alg_bytes[dominant] * args.particles / (mean_ms[dominant] * 1e-3) / 1e9 if mean_ms[dominant] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_particle_update": alg_bytes[dominant],
+                "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,
+                "achieved_stored_bytes_GBs": ach / 4.0,
+                "kernel_ms_mean": mean_ms, "slow_cells_per_step": c["slow_cells"] / n_upd,
+                "unique_cells_written_per_particle": W_per_particle,
+                "ray_cells_per_particle": cells_per_particle}
+    out = {"metric": "particle-updates/sec (particles x scans/s) @1081 beams", "value": value,
+           "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "int8 map cells (lattice log-odds), f64 poses/weights", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[1]: room16 synthetic, {args.particles} particles/GPU, "
+                                  f"{args.beams} beams, {args.cell_size} m grid, K=30 samples, resample every step",
+                      "particles_per_gpu": args.particles, "beams": args.beams, "cell_size": args.cell_size,
+                      "parallelism": f"particles sharded x{world}"},
+           "roofline": roofline}
+    run.e.close()
+    if not args.no_target_run and world == 1:
+        # north-star target size: >= 10k particles x 1081 beams on one GPU (not `value`)
+        big = Runner(10240, args.beams, args.cell_size, log)
+        for _ in range(3):
+            big.step()
+        big.e.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = min(args.steps, 20)
+        for _ in range(nb):
+            big.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        km = {k: float(big.e.kernel_ms(k).mean()) for k in ("raycast", "weight", "resample", "match", "ray_setup")}
+        cb = big.e.counters()
+        Wb = cb["cells_written"] / (nb * 10240)
+        out["target_10k"] = {"particles": 10240, "value": 10240 * nb / dt, "ms_per_step": 1e3 * dt / nb,
+                             "kernel_ms_mean": km,
+                             "raycast_frac_of_hbm_peak": 8.0 * Wb * 10240 / (km["raycast"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        big.e.close()
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(log, args.beams, args.cell_size)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

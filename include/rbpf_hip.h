@@ -78,12 +78,13 @@ typedef struct rbpf_config {
 } rbpf_config;
 
 typedef struct rbpf_counters {
+    /* cumulative since rbpf_create or the last rbpf_set_profiling call: */
     uint64_t scan_updates;        /* rbpf_scan_update/rbpf_map_update calls                       */
-    uint64_t ray_cells_visited;   /* sum of Bresenham points over all rays of the last update     */
-    uint64_t cells_written;       /* unique cells written by the last update  (|W| summed over P) */
-    uint64_t cells_gathered;      /* beam-endpoint gathers of the last weighting (P*K*valid B)    */
-    uint64_t tiles_in_use;        /* tiles allocated from the pool                                */
-    uint64_t resample_copies;     /* tile copies made by the last resample                        */
+    uint64_t ray_cells_visited;   /* sum of Bresenham points over all rays                        */
+    uint64_t cells_written;       /* unique cells written per update, summed (|W| over particles) */
+    uint64_t cells_gathered;      /* reserved                                                     */
+    uint64_t tiles_in_use;        /* tiles allocated from the pool (current)                      */
+    uint64_t resample_copies;     /* tile copies made by resampling                               */
     uint64_t bytes_copied;        /* bytes moved by those copies (read + write)                   */
     double   ms_raycast;          /* HIP-event time of the last ray-cast kernel                   */
     double   ms_weight;           /* ... of the last weighting kernel                             */
@@ -102,7 +103,11 @@ const char* rbpf_last_error(const rbpf_handle* h);   /* h may be NULL (create fa
 int  rbpf_set_stream(rbpf_handle* h, void* hip_stream); /* e.g. torch's current stream        */
 int  rbpf_synchronize(rbpf_handle* h);
 int  rbpf_get_counters(rbpf_handle* h, rbpf_counters* out);
-int  rbpf_set_profiling(rbpf_handle* h, int on);     /* per-kernel HIP events -> counters     */
+int  rbpf_set_profiling(rbpf_handle* h, int on);     /* per-kernel HIP events; resets the rings */
+/* durations (ms) of the launches recorded since rbpf_set_profiling, HIP events on the handle's stream;
+ * which: 0 ray-cast window kernel, 1 proposal/weighting kernel, 2 resample kernels, 3 scan-match kernel,
+ * 4 ray setup kernel.  Synchronises the stream. */
+int  rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t cap, int32_t* n_out);
 
 /* ---- a1: scan geometry (Scan.__init__, lidar.py:76-80) ------------------------------------ */
 /* ranges[B], angles[B] -> sensor-frame endpoints (host libm cos/sin, as the reference), the

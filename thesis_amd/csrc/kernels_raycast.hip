@@ -169,18 +169,20 @@ struct WinShared {
     uint32_t* cnt;    // [WIN*WIN/2] two 16-bit hit counters per word; flagged cells hold their bucket id
     uint32_t* flag;   // [WIN*WIN/32]
     uint32_t* bcnt;   // [NB] events appended per bucket
-    uint16_t* bev;    // [NB*EV_CAP] (beam << 3) | rank
+    uint16_t* bev;    // [EV_TOT] (beam << 3) | rank, bucket id at [id * cap, (id + 1) * cap), cap chosen per window
     uint16_t* bcell;  // [NB] local cell index of the bucket
+    uint16_t* slowc;  // [NB] local cell indices left to the wave-cooperative replay
     int16_t*  lutx;   // [WIN+8] global x offset -> local storage x
     int16_t*  luty;
 };
 
 static const int NB_MAX = 2304;
+static const int EV_TOT = 10240;        // event slots per window, shared out evenly among its flagged cells
 __host__ __device__ inline int raycast_nb(int B) { int nb = 2 * B; return nb < NB_MAX ? nb : NB_MAX; }
 
 size_t raycast_lds_bytes(int B) {
     size_t nb = raycast_nb(B);
-    return (size_t)WIN * WIN / 2 * 4 + (size_t)WIN * WIN / 32 * 4 + nb * 4 + nb * EV_CAP * 2 + nb * 2 +
+    return (size_t)WIN * WIN / 2 * 4 + (size_t)WIN * WIN / 32 * 4 + nb * 4 + (size_t)EV_TOT * 2 + nb * 2 + nb * 2 +
            2 * (WIN + 8) * 2 + 64;
 }
 
@@ -240,6 +242,74 @@ __device__ int replay_cell_slow(const DevView& v, const int32_t* __restrict__ ra
     return val;
 }
 
+// Clamped-add functions v -> min(max(v + a, lo), hi) are closed under composition, so the ordered
+// sequence of a cell's events can be folded associatively: each lane folds the events of one beam, the
+// wave folds 64 beams in beam order with a shuffle tree.
+struct Caf { int a, lo, hi; };
+__device__ __forceinline__ Caf caf_then(Caf f, Caf g) {          // g after f
+    Caf r;
+    r.a = f.a + g.a;
+    int lo = f.lo + g.a; lo = lo < g.lo ? g.lo : lo; r.lo = lo > g.hi ? g.hi : lo;
+    int hi = f.hi + g.a; hi = hi < g.lo ? g.lo : hi; r.hi = hi > g.hi ? g.hi : hi;
+    return r;
+}
+__device__ __forceinline__ int caf_apply(Caf f, int x) { int t = x + f.a; t = t < f.lo ? f.lo : t; return t > f.hi ? f.hi : t; }
+
+__device__ int replay_cell_wave(const DevView& v, const int32_t* __restrict__ rays, int x0, int y0, const int* gxc,
+                                int ngx, const int* gyc, int ngy, int val, int lane) {
+    const int BIG = 1000000;
+    const Caf fE = {v.cc.emp, v.cc.vmin, BIG}, fO = {v.cc.occ, -BIG, v.cc.vmax}, fN = {v.cc.nearby, -BIG, v.cc.vmax};
+    for (int base = 0; base < v.B; base += 64) {
+        const int b = base + lane;
+        Caf f = {0, -BIG, BIG};
+        bool has = false;
+        if (b < v.B) {
+            int x1, y1;
+            unpack_end(rays[b], x0, y0, x1, y1);
+            Ray r = ray_make(x0, y0, x1, y1);
+            if (r.n > 0) {
+                const bool occ = !(v.bflags[b] & BF_LONG);
+                int js[4], nj = 0;
+                for (int ix = 0; ix < ngx; ++ix)
+                    for (int iy = 0; iy < ngy; ++iy) {
+                        int gx = gxc[ix], gy = gyc[iy];
+                        int j = r.steep ? (gy - y0) * r.sy : (gx - x0) * r.sx;
+                        if (j < 0 || j >= r.n) continue;
+                        int qx, qy;
+                        ray_point(r, j, qx, qy);
+                        if (qx == gx && qy == gy) js[nj++] = j;
+                    }
+                for (int a = 1; a < nj; ++a) {
+                    int key = js[a], c = a - 1;
+                    while (c >= 0 && js[c] > key) { js[c + 1] = js[c]; --c; }
+                    js[c + 1] = key;
+                }
+                bool near_here = false;
+                for (int a = 0; a < nj; ++a) {
+                    int j = js[a];
+                    f = caf_then(f, (j == r.n - 1 && occ) ? fO : fE);
+                    if (occ && r.n >= 2 && j == r.n - 2) {
+                        int nx, ny;
+                        ray_point(r, j, nx, ny);
+                        near_here = same_tile(v, nx, ny, x1, y1);
+                    }
+                }
+                if (near_here) f = caf_then(f, fN);
+                has = nj > 0;
+            }
+        }
+        if (__ballot(has) == 0ull) continue;
+        for (int off = 1; off < 64; off <<= 1) {
+            Caf g;
+            g.a = __shfl_down(f.a, off, 64); g.lo = __shfl_down(f.lo, off, 64); g.hi = __shfl_down(f.hi, off, 64);
+            if ((lane & (2 * off - 1)) == 0) f = caf_then(f, g);
+        }
+        val = caf_apply(f, val);        // lane 0 holds the fold of the whole chunk
+        val = __shfl(val, 0, 64);
+    }
+    return val;
+}
+
 __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* __restrict__ queue_head) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int NB = raycast_nb(v.B);
@@ -248,10 +318,11 @@ __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* _
     s.flag = s.cnt + WIN * WIN / 2;
     s.bcnt = s.flag + WIN * WIN / 32;
     s.bev = reinterpret_cast<uint16_t*>(s.bcnt + NB);
-    s.bcell = s.bev + (size_t)NB * EV_CAP;
-    s.lutx = reinterpret_cast<int16_t*>(s.bcell + NB);
+    s.bcell = s.bev + EV_TOT;
+    s.slowc = s.bcell + NB;
+    s.lutx = reinterpret_cast<int16_t*>(s.slowc + NB);
     s.luty = s.lutx + (WIN + 8);
-    __shared__ int s_item, s_nflag, s_g[4], s_bb[4], s_written, s_slow;
+    __shared__ int s_item, s_nflag, s_g[4], s_bb[4], s_written, s_slow, s_nslow;
     const int tid = threadIdx.x;
     const size_t tile_cells = (size_t)v.dim * v.dim;
 
@@ -283,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* _
             s_g[tid] = lut_lower_bound(v, key);
         }
         if (tid == 0) {
-            s_nflag = 0; s_written = 0; s_slow = 0;
+            s_nflag = 0; s_written = 0; s_slow = 0; s_nslow = 0;
             s_bb[0] = INT_MAX; s_bb[1] = -1; s_bb[2] = INT_MAX; s_bb[3] = -1;
         }
         __syncthreads();
@@ -327,6 +398,11 @@ __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* _
         }
         __syncthreads();
 
+        // event slots are shared out evenly: few flagged cells (a near wall under dense beams) get deep buckets
+        const int nflag = s_nflag;
+        const int cap = min(64, max(4, EV_TOT / max(nflag, 1)));
+        const int nbk = min(min(nflag, NB), EV_TOT / cap);
+
         // ---- phase 2: walk the clipped rays ------------------------------------------------------------
         for (int b = tid; b < v.B; b += BLOCK) {
             int x1, y1;
@@ -367,14 +443,14 @@ __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* _
                     int c = s.lutx[ix] * WIN + s.luty[iy];
                     if (flag_get(s.flag, c)) {
                         uint32_t id = cnt16_get(s.cnt, c);
-                        if (id != 0xFFFFu) {
+                        if ((int)id < nbk) {
                             int rem = r.n - 1 - j;
                             int rank = (rem == 0) ? (occ ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
                             uint32_t pos = atomicAdd(&s.bcnt[id], 1u);
-                            if (pos < EV_CAP) s.bev[id * EV_CAP + pos] = (uint16_t)((b << 3) | rank);
+                            if ((int)pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | rank);
                             if (near_ok && rem == 1) {
                                 pos = atomicAdd(&s.bcnt[id], 1u);
-                                if (pos < EV_CAP) s.bev[id * EV_CAP + pos] = (uint16_t)((b << 3) | EV_NEAR);
+                                if ((int)pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | EV_NEAR);
                             }
                         }
                     } else {
@@ -417,44 +493,35 @@ __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* _
         }
         __syncthreads();   // flagged cells share 32-bit words with phase-3a cells: finish 3a first
 
-        // ---- phase 3b: flagged cells, ordered replay ---------------------------------------------------
-        const int nflag = s_nflag;
-        const int nbucket = min(nflag, NB);
-        for (int id = tid; id < nbucket; id += BLOCK) {
+        // ---- phase 3b: flagged cells, ordered replay from their buckets ----------------------------------
+        for (int id = tid; id < min(nflag, NB); id += BLOCK) {
             const int c = s.bcell[id];
+            const int m = id < nbk ? (int)s.bcnt[id] : INT_MAX;
+            if (m > cap) { s.slowc[atomicAdd(&s_nslow, 1)] = (uint16_t)c; continue; }   // bucket overflow / no bucket
             const int lx = c / WIN, ly = c % WIN;
             int8_t* gp = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
             int val = *gp;
-            const int m = (int)s.bcnt[id];
-            if (m <= EV_CAP) {
-                // replay in ascending (beam, rank): selection by repeated minimum, m is tiny
-                uint32_t last = 0; bool first = true;
-                for (int k = 0; k < m; ++k) {
-                    uint32_t best = 0xFFFFFFFFu;
-                    int dup = 0;
-                    for (int e = 0; e < m; ++e) {
-                        uint32_t key = s.bev[id * EV_CAP + e];
-                        if (!first && key <= last) continue;
-                        if (key < best) { best = key; dup = 1; } else if (key == best) ++dup;
-                    }
-                    if (best == 0xFFFFFFFFu) break;
-                    for (int d = 0; d < dup; ++d) val = cell_apply_rank(val, (int)(best & 7u), v.cc);
-                    k += dup - 1;
-                    last = best; first = false;
+            // replay in ascending (beam, rank): selection by repeated minimum, m is small
+            uint32_t last = 0; bool first = true;
+            for (int k = 0; k < m; ++k) {
+                uint32_t best = 0xFFFFFFFFu;
+                int dup = 0;
+                for (int e = 0; e < m; ++e) {
+                    uint32_t key = s.bev[id * cap + e];
+                    if (!first && key <= last) continue;
+                    if (key < best) { best = key; dup = 1; } else if (key == best) ++dup;
                 }
-            } else {
-                int gxc[4], gyc[4], ngx = 0, ngy = 0;
-                for (int i = 0; i < gxb - gxa && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
-                for (int i = 0; i < gyb - gya && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
-                val = replay_cell_slow(v, rays, x0, y0, gxc, ngx, gyc, ngy, val);
-                atomicAdd(&s_slow, 1);
+                if (best == 0xFFFFFFFFu) break;
+                for (int d = 0; d < dup; ++d) val = cell_apply_rank(val, (int)(best & 7u), v.cc);
+                k += dup - 1;
+                last = best; first = false;
             }
             *gp = (int8_t)val;
             ++my_written;
             bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
             by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
         }
-        if (nflag > NB) {   // more flagged cells than buckets: the rest go through the slow path
+        if (nflag > NB) {   // more flagged cells than bucket ids
             for (int w = tid; w < WIN * WIN / 32; w += BLOCK) {
                 uint32_t bits = s.flag[w];
                 while (bits) {
@@ -462,18 +529,43 @@ __global__ __launch_bounds__(BLOCK) void raycast_window_kernel(DevView v, int* _
                     bits &= bits - 1;
                     int c = w * 32 + bit;
                     if (cnt16_get(s.cnt, c) != 0xFFFFu) continue;
-                    const int lx = c / WIN, ly = c % WIN;
-                    int8_t* gp = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
-                    int gxc[4], gyc[4], ngx = 0, ngy = 0;
-                    for (int i = 0; i < gxb - gxa && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
-                    for (int i = 0; i < gyb - gya && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
-                    *gp = (int8_t)replay_cell_slow(v, rays, x0, y0, gxc, ngx, gyc, ngy, (int)*gp);
-                    atomicAdd(&s_slow, 1);
+                    int k = atomicAdd(&s_nslow, 1);
+                    if (k < NB) s.slowc[k] = (uint16_t)c;
+                    else {      // beyond every list: one lane replays it alone (never seen in practice)
+                        const int lx = c / WIN, ly = c % WIN;
+                        int8_t* gp = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
+                        int gxc[4], gyc[4], ngx = 0, ngy = 0;
+                        for (int i = 0; i < gxb - gxa && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
+                        for (int i = 0; i < gyb - gya && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
+                        *gp = (int8_t)replay_cell_slow(v, rays, x0, y0, gxc, ngx, gyc, ngy, (int)*gp);
+                        ++my_written;
+                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+                        by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 3c: cells without a usable bucket: one wave each, exact membership scan over all beams ----
+        {
+            const int nslow = min(s_nslow, NB);
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int k = wave; k < nslow; k += BLOCK / 64) {
+                const int c = s.slowc[k];
+                const int lx = c / WIN, ly = c % WIN;
+                int8_t* gp = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
+                int gxc[4], gyc[4], ngx = 0, ngy = 0;
+                for (int i = 0; i < gxb - gxa && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
+                for (int i = 0; i < gyb - gya && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
+                int val = replay_cell_wave(v, rays, x0, y0, gxc, ngx, gyc, ngy, (int)*gp, lane);
+                if (lane == 0) {
+                    *gp = (int8_t)val;
                     ++my_written;
                     bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
                     by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
                 }
             }
+            if (tid == 0) s_slow = nslow;
         }
         // ---- phase 4: bounding box of written cells (bounds resample copies), counters -----------------
         if (my_written) {
@@ -497,10 +589,12 @@ int raycast_items_cap(const rbpf_config& cfg) {
     return nwin * nwin;
 }
 
-void launch_map_update(const DevView& v, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    // queue head lives right behind n_items
-    (void)hipMemsetAsync(v.n_items, 0, 2 * sizeof(int32_t), s);
+void launch_ray_setup(const DevView& v, hipStream_t s) {
+    (void)hipMemsetAsync(v.n_items, 0, 2 * sizeof(int32_t), s);      // item count + queue head
     hipLaunchKernelGGL(ray_setup_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, v.items_cap);
+}
+
+void launch_raycast_windows(const DevView& v, hipStream_t s) {
     size_t lds = raycast_lds_bytes(v.B);
     int blocks_per_cu = (int)(160 * 1024 / (lds + 256));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -509,12 +603,10 @@ void launch_map_update(const DevView& v, hipStream_t s, hipEvent_t e0, hipEvent_
     static size_t lds_attr = 0;
     if (lds > lds_attr) {   // more than the default 64 KiB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(raycast_window_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    if (e0) (void)hipEventRecord(e0, s);
     hipLaunchKernelGGL(raycast_window_kernel, dim3(grid), dim3(BLOCK), lds, s, v, v.n_items + 1);
-    if (e1) (void)hipEventRecord(e1, s);
 }
 
 }  // namespace rbpf

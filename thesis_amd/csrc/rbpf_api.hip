@@ -161,7 +161,11 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     auto build = [&]() -> int {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
-        for (auto& ev : h->ev) HIP_TRY(h, hipEventCreate(&ev));
+        for (int k = 0; k < rbpf_handle::N_KERN; ++k)
+            for (int e = 0; e < 2; ++e) {
+                h->ring[k][e].resize(rbpf_handle::RING);
+                for (auto& ev : h->ring[k][e]) HIP_TRY(h, hipEventCreate(&ev));
+            }
         const size_t P = v.P, LL = (size_t)v.L * v.L, cells = (size_t)dim * dim;
         uint32_t* d_lut; ALLOC(h, d_lut, h->h_lut.size()); v.lut = d_lut;
         HIP_TRY(h, hipMemcpy(d_lut, h->h_lut.data(), h->h_lut.size() * 4, hipMemcpyHostToDevice));
@@ -228,7 +232,7 @@ int rbpf_destroy(rbpf_handle* h) {
     if (h->d_prs) hipFree(h->d_prs);
     if (h->d_w) hipFree(h->d_w);
     if (h->h_pinned) hipHostFree(h->h_pinned);
-    for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
+    for (int k = 0; k < rbpf_handle::N_KERN; ++k) for (int e = 0; e < 2; ++e) for (auto& ev : h->ring[k][e]) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return RBPF_OK;
@@ -253,6 +257,25 @@ int rbpf_synchronize(rbpf_handle* h) {
 int rbpf_set_profiling(rbpf_handle* h, int on) {
     if (!h) return RBPF_EINVAL;
     h->profiling = on != 0;
+    for (int k = 0; k < rbpf_handle::N_KERN; ++k) h->ring_n[k] = 0;
+    HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, 8 * sizeof(unsigned long long), h->stream));   // counters restart
+    return RBPF_OK;
+}
+
+int rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t cap, int32_t* n_out) {
+    if (!h || !n_out || which < 0 || which >= rbpf_handle::N_KERN) return RBPF_EINVAL;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int n = std::min(h->ring_n[which], rbpf_handle::RING);
+    int first = h->ring_n[which] - n;
+    int m = 0;
+    for (int i = 0; i < n && m < cap; ++i) {
+        int slot = (first + i) % rbpf_handle::RING;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ring[which][0][slot], h->ring[which][1][slot]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (out_ms) out_ms[m] = ms;
+        ++m;
+    }
+    *n_out = m;
     return RBPF_OK;
 }
 
@@ -270,11 +293,13 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.resample_copies = st[ST_COPIES]; c.bytes_copied = st[ST_COPY_BYTES];
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
     if (h->profiling) {
-        float ms = 0;
-        if (h->ev_recorded[0] && hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) c.ms_raycast = ms;
-        if (h->ev_recorded[1] && hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) c.ms_weight = ms;
-        if (h->ev_recorded[2] && hipEventElapsedTime(&ms, h->ev[4], h->ev[5]) == hipSuccess) c.ms_resample = ms;
-        if (h->ev_recorded[3] && hipEventElapsedTime(&ms, h->ev[6], h->ev[7]) == hipSuccess) c.ms_match = ms;
+        double* dst[4] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match};
+        for (int k = 0; k < 4; ++k) {
+            if (h->ring_n[k] == 0) continue;
+            int slot = (h->ring_n[k] - 1) % rbpf_handle::RING;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->ring[k][0][slot], h->ring[k][1][slot]) == hipSuccess) *dst[k] = ms;
+        }
         (void)hipGetLastError();
     }
     *out = c;
@@ -356,9 +381,9 @@ int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_guess, guesses, n * 3 * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_prs, prs, n * 8, hipMemcpyHostToDevice, h->stream));
-    if (h->profiling) (void)hipEventRecord(h->ev[2], h->stream);
+    h->prof_begin(1);
     launch_weight_samples(h->v, h->d_guess, h->d_prs, K, h->d_w, h->stream);
-    if (h->profiling) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_recorded[1] = true; }
+    h->prof_end(1);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out_w, h->d_w, n * 8, hipMemcpyDeviceToHost, h->stream));
     return check_device_error(h);
@@ -367,12 +392,12 @@ int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs
 // ---- a5 test entry --------------------------------------------------------------------------------------
 static int run_map_update(rbpf_handle* h) {
     DevView& v = h->v;
-    HIP_TRY(h, hipMemsetAsync(v.stats, 0, 2 * sizeof(unsigned long long), h->stream));   // ray cells, cells written
-    HIP_TRY(h, hipMemsetAsync(&v.stats[ST_SLOW_CELLS], 0, sizeof(unsigned long long), h->stream));
-    static bool attr_set = false;
-    (void)attr_set;
-    launch_map_update(v, h->stream, h->profiling ? h->ev[0] : nullptr, h->profiling ? h->ev[1] : nullptr);
-    if (h->profiling) h->ev_recorded[0] = true;
+    h->prof_begin(4);
+    launch_ray_setup(v, h->stream);
+    h->prof_end(4);
+    h->prof_begin(0);
+    launch_raycast_windows(v, h->stream);
+    h->prof_end(0);
     HIP_TRY(h, hipGetLastError());
     h->scan_updates++;
     return RBPF_OK;
@@ -403,10 +428,10 @@ static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, 
     if (adj && (!last_scan_xy || n_last < 0 || n_last > h->cfg.max_beams))
         return fail(h, RBPF_EINVAL, "adj = 1 needs last_scan_xy with at most max_beams points");
     if (adj) HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, last_scan_xy, (size_t)n_last * 16, hipMemcpyHostToDevice, h->stream));
-    if (h->profiling) (void)hipEventRecord(h->ev[6], h->stream);
+    h->prof_begin(3);
     launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
                            h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, h->stream);
-    if (h->profiling) { (void)hipEventRecord(h->ev[7], h->stream); h->ev_recorded[3] = true; }
+    h->prof_end(3);
     HIP_TRY(h, hipGetLastError());
     return RBPF_OK;
 }
@@ -429,9 +454,9 @@ int rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, in
         HIP_TRY(h, hipMemcpyAsync(h->d_guess_full, guesses, P * (size_t)v.K * 3 * 8, hipMemcpyHostToDevice, h->stream));
         d_g = h->d_guess_full;
     }
-    if (h->profiling) (void)hipEventRecord(h->ev[2], h->stream);
+    h->prof_begin(1);
     launch_propose_weight(v, h->d_match, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
-    if (h->profiling) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_recorded[1] = true; }
+    h->prof_end(1);
     int rc = run_map_update(h);                 // HybridMap.update at the new mean pose (robot.py:115)
     if (rc) return rc;
     launch_bad_weight(v, h->d_bad, h->stream);  // robot.py:73-78 fallback, after the map update
@@ -503,11 +528,10 @@ int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resam
     DevView& v = h->v;
     if (u != u) u = internal_uniform(h);
     if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
-    HIP_TRY(h, hipMemsetAsync(&v.stats[ST_COPIES], 0, 2 * sizeof(unsigned long long), h->stream));
-    if (h->profiling) (void)hipEventRecord(h->ev[4], h->stream);
+    h->prof_begin(2);
     launch_resample_indices(v.P, v.weight, u, h->cfg.resample_spread, h->rs.T, h->rs.idx, h->rs.did, v.err, h->stream);
     launch_resample_apply(v, h->rs, h->stream);
-    if (h->profiling) { (void)hipEventRecord(h->ev[5], h->stream); h->ev_recorded[2] = true; }
+    h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
     if (idx_out) HIP_TRY(h, hipMemcpyAsync(idx_out, h->rs.idx, (size_t)v.P * 4, hipMemcpyDeviceToHost, h->stream));

@@ -12,7 +12,6 @@ namespace rbpf {
 
 static const int BLOCK = 256;          // 4 waves of 64
 static const int WIN = 128;            // LDS window edge (storage cells)
-static const int EV_CAP = 6;           // ordered events kept per flagged cell before the slow path
 static const int MAX_ITEMS_PER_PARTICLE = 64;
 
 // beam range classes, computed on the host from the float64 distance (rbpf_set_scan)
@@ -90,8 +89,12 @@ struct rbpf_handle {
     double* d_last_xy = nullptr; float* d_tmp_sel = nullptr;
     double* d_match = nullptr; uint8_t* d_bad = nullptr; double* d_guess_full = nullptr;
     unsigned long long resample_draws = 0;
-    hipEvent_t ev[8];
-    bool ev_recorded[4] = {false, false, false, false};
+    // profiling: a ring of HIP-event pairs per kernel family, recorded on the handle's stream
+    static const int N_KERN = 5, RING = 512;        // 0 ray-cast windows, 1 propose/weight, 2 resample, 3 match, 4 ray setup
+    std::vector<hipEvent_t> ring[N_KERN][2];
+    int ring_n[N_KERN] = {0, 0, 0, 0, 0};
+    hipEvent_t prof_begin(int k) { if (!profiling) return nullptr; hipEvent_t e = ring[k][0][ring_n[k] % RING]; (void)hipEventRecord(e, stream); return e; }
+    void prof_end(int k) { if (!profiling) return; (void)hipEventRecord(ring[k][1][ring_n[k] % RING], stream); ring_n[k]++; }
     rbpf::ResampleBuffers rs;
     rbpf_counters counters;
     unsigned long long scan_updates = 0;
@@ -101,7 +104,8 @@ namespace rbpf {
 // kernel launchers (one translation unit per kernel family)
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
-void launch_map_update(const DevView& v, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+void launch_ray_setup(const DevView& v, hipStream_t s);
+void launch_raycast_windows(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
 void launch_imu_update(const DevView& v, int model, double d0, double d1, double d2, double dt_ticks,

@@ -93,6 +93,16 @@ class ParticleEngine:
     def set_profiling(self, on: bool):
         self._check(self._lib.rbpf_set_profiling(self._h, int(on)))
 
+    KERNELS = {"raycast": 0, "weight": 1, "resample": 2, "match": 3, "ray_setup": 4}
+
+    def kernel_ms(self, which) -> np.ndarray:
+        """Per-launch durations (ms, HIP events on the engine's stream) since set_profiling(True)."""
+        k = self.KERNELS[which] if isinstance(which, str) else int(which)
+        out = np.empty(512)
+        n = C.c_int32()
+        self._check(self._lib.rbpf_get_kernel_ms(self._h, k, _dp(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
     def counters(self) -> Dict[str, float]:
         c = RbpfCounters()
         self._check(self._lib.rbpf_get_counters(self._h, C.byref(c)))
@@ -145,6 +155,10 @@ class ParticleEngine:
         did = C.c_int32()
         self._check(self._lib.rbpf_resample(self._h, float(u), _ip(idx), C.byref(did)))
         return bool(did.value), idx
+
+    def resample_async(self, u: float = float("nan")):
+        """resample without reading the ancestor indices back (no host synchronisation)."""
+        self._check(self._lib.rbpf_resample(self._h, float(u), None, None))
 
     # -- state ---------------------------------------------------------------------------------------
     def poses(self) -> np.ndarray:
