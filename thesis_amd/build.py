@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librbpf_hip.so")
-SOURCES = ["rbpf_api.hip", "kernels_weight.hip", "kernels_raycast.hip", "kernels_state.hip",
+SOURCES = ["rbpf_api.hip", "kernels_weight.hip", "kernels_mapupdate.hip", "kernels_state.hip",
            "kernels_propose.hip", "kernels_resample.hip", "kernels_match.hip"]
 HEADERS = ["rbpf_internal.h", "rbpf_math.h", "rbpf_device.h", os.path.join("..", "..", "include", "rbpf_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
@@ -32,10 +32,11 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = ["-DRBPF_STAMPS"] if os.environ.get("RBPF_STAMPS") else []   # diagnostic build: per-phase cycle stamps
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

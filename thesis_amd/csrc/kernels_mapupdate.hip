@@ -1,0 +1,644 @@
+// kernels_mapupdate.hip -- a5: HybridMap.update (hybridmap.py:95-145) for all particles, one kernel.
+//
+// One 512-thread workgroup per particle.
+//
+//  setup     transforms the B beam endpoints (lidar.py:111-128), forms the integer start/end cells
+//            (hybridmap.py:102-113) and keeps them in LDS (4 B + 1 B per ray); decides exactly which
+//            lattice tiles the rays enter (the reference creates a tile when the first ray cell falls
+//            into it, hybridmap.py:124-133) and allocates them from the pool.
+//
+//  windows   the workgroup then walks the 128x128-cell windows of the touched tiles that the ray fan's
+//            bounding box overlaps.  A window is staged in LDS as 16-bit hit counters.  Rays are clipped to
+//            the window with the closed form of the reference's Bresenham (rbpf_math.h), so every ray
+//            cell is visited exactly once over all windows.  The reference applies clamped adds in beam
+//            order (hybridmap.py:103, gridmap.py:86-117); that order matters only for cells that receive an
+//            "occupied" or "nearby" hit in this scan.  Those cells are flagged first; hits on them are kept
+//            as (beam, rank) events in per-cell LDS buckets (the window's event slots are shared out evenly
+//            among its flagged cells) and replayed in order.  All other cells only receive "empty" hits,
+//            which commute: max(v + n*emp, min).  A cell whose bucket overflows is replayed by one wave
+//            with an exact closed-form membership test over all beams, folded in beam order with the
+//            associative composition of clamped adds.  The result is bit-identical to the sequential
+//            reference on the int8 lattice.
+//
+// HBM traffic: per window only the 4-byte words that contain a touched cell are read and written;
+// roofline = HBM (read-modify-write of the touched cells), no MFMA.
+#include <limits.h>
+
+#include "rbpf_internal.h"
+#include "rbpf_device.h"
+
+namespace rbpf {
+
+// Diagnostic build only (-DRBPF_STAMPS): thread 0 of every workgroup sums the cycles between phase boundaries;
+// the sums go to the reserved counters and are never read by the kernel.
+#ifdef RBPF_STAMPS
+#define STAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+static const int MU_BLOCK = 512;       // 8 waves per particle
+static const int NB_MAX = 2304;        // bucket ids per window
+static const int EV_TOT = 6144;        // event slots per window
+static const int CHUNK = 32;           // ray steps per work item of the walk
+static const int SMALL_BUCKET = 8;     // buckets up to this size are replayed by one lane from registers
+
+__host__ __device__ inline int mu_nb(int B) { int nb = 2 * B; return nb < NB_MAX ? nb : NB_MAX; }
+// chunk table entries: every ray has at most ceil((WIN + 2) / CHUNK) = 5 chunks in a window; the same memory later
+// holds the two replay work lists (NB deep buckets + the overflow list)
+__host__ __device__ inline int mu_chunk_cap(int B) { int a = 5 * B, b = 2 * mu_nb(B) + 64; int c = a > b ? a : b; return (c + 7) & ~7; }
+
+size_t raycast_lds_bytes(int B) {
+    size_t nb = mu_nb(B);
+    size_t bpad = (size_t)((B + 3) & ~3);
+    size_t bytes = (size_t)WIN * WIN / 2 * 4 + (size_t)WIN * WIN / 32 * 4 + (size_t)WIN * WIN / 32 * 2 + (size_t)EV_TOT * 2 + nb * 2 +
+                   (size_t)mu_chunk_cap(B) * 2 + 2 * (WIN + 8) * 2 + bpad * 4 + bpad * 2 * 2 + (size_t)((B + 15) & ~15);
+    return (bytes + 15) & ~(size_t)15;
+}
+
+// per-ray info byte
+enum { RI_VALID = 1, RI_OCC = 2, RI_NEAR = 4 };   // bits 3-4: near dx + 1, bits 5-6: near dy + 1
+
+struct MuLds {
+    uint32_t* cnt;    // [WIN*WIN/2] two 16-bit hit counters per word; flagged cells hold their bucket id
+    uint32_t* flag;   // [WIN*WIN/32]
+    uint16_t* fpre;   // [WIN*WIN/32] flagged cells before each flag word (bucket id = rank in cell order)
+    uint16_t* bev;    // [EV_TOT] (beam << 3) | rank; bucket id at [id*cap, (id+1)*cap)
+    uint16_t* bcell;  // [NB] local cell index of bucket id
+    uint16_t* chunk;  // [CH_CAP] walk work items (beam << 3) | chunk; later the replay work lists
+    int16_t*  lutx;   // [WIN+8]
+    int16_t*  luty;
+    int32_t*  r_end;  // [B] packed (dx & 0xFFFF) | (dy << 16) relative to the start cell
+    int16_t*  seg_lo; // [B] first / last step of the ray inside the current window
+    int16_t*  seg_hi;
+    uint8_t*  r_info; // [B]
+};
+
+__device__ __forceinline__ uint32_t cnt16_get(const uint32_t* cnt, int c) { return (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu; }
+__device__ __forceinline__ void cnt16_set(uint32_t* cnt, int c, uint32_t val) { reinterpret_cast<uint16_t*>(cnt)[c] = (uint16_t)val; }
+__device__ __forceinline__ bool flag_get(const uint32_t* flag, int c) { return (flag[c >> 5] >> (c & 31)) & 1u; }
+
+// same-tile test of hybridmap.py:141 (m.is_in_map(nearby_pos) with m = tile of the end cell)
+__device__ __forceinline__ bool same_tile(const DevView& v, int xa, int ya, int xb, int yb) {
+    return lut_lat(lut_at(v, xa)) == lut_lat(lut_at(v, xb)) && lut_lat(lut_at(v, ya)) == lut_lat(lut_at(v, yb));
+}
+
+// first j with minor offset >= m (m >= 1, dmin > 0), 32-bit (2*dmaj*m < 2^31 for rays shorter than a tile)
+__device__ __forceinline__ int first_j_minor_ge(const Ray& r, int m) {
+    int num = 2 * r.dmaj * m - r.dmaj, den = 2 * r.dmin;
+    return (num + den - 1) / den;
+}
+__device__ __forceinline__ int last_j_minor_le(const Ray& r, int m) {
+    int num = 2 * r.dmaj * (m + 1) - r.dmaj - 1;
+    if (num < 0) return -1;
+    int j = num / (2 * r.dmin);
+    return j > r.dmaj ? r.dmaj : j;
+}
+
+// Clamped-add functions v -> min(max(v + a, lo), hi) are closed under composition, so the ordered sequence of
+// a cell's events folds associatively: each lane folds the events of one beam, the wave folds 64 beams in
+// beam order with a shuffle tree.
+struct Caf { int a, lo, hi; };
+__device__ __forceinline__ Caf caf_then(Caf f, Caf g) {          // g after f
+    Caf r;
+    r.a = f.a + g.a;
+    int lo = f.lo + g.a; lo = lo < g.lo ? g.lo : lo; r.lo = lo > g.hi ? g.hi : lo;
+    int hi = f.hi + g.a; hi = hi < g.lo ? g.lo : hi; r.hi = hi > g.hi ? g.hi : hi;
+    return r;
+}
+__device__ __forceinline__ int caf_apply(Caf f, int x) { int t = x + f.a; t = t < f.lo ? f.lo : t; return t > f.hi ? f.hi : t; }
+
+__device__ int replay_cell_wave(const DevView& v, const MuLds& s, int x0, int y0, const int* gxc, int ngx,
+                                const int* gyc, int ngy, int val, int lane) {
+    const int BIG = 1000000;
+    const Caf fE = {v.cc.emp, v.cc.vmin, BIG}, fO = {v.cc.occ, -BIG, v.cc.vmax}, fN = {v.cc.nearby, -BIG, v.cc.vmax};
+    for (int base = 0; base < v.B; base += 64) {
+        const int b = base + lane;
+        Caf f = {0, -BIG, BIG};
+        bool has = false;
+        if (b < v.B && (s.r_info[b] & RI_VALID)) {
+            const int info = s.r_info[b];
+            int x1, y1;
+            unpack_end(s.r_end[b], x0, y0, x1, y1);
+            Ray r = ray_make(x0, y0, x1, y1);
+            const bool occ = info & RI_OCC;
+            int js[4], nj = 0;
+            for (int ix = 0; ix < ngx; ++ix)
+                for (int iy = 0; iy < ngy; ++iy) {
+                    int gx = gxc[ix], gy = gyc[iy];
+                    int j = r.steep ? (gy - y0) * r.sy : (gx - x0) * r.sx;
+                    if (j < 0 || j >= r.n) continue;
+                    int qx, qy;
+                    ray_point(r, j, qx, qy);
+                    if (qx == gx && qy == gy) js[nj++] = j;
+                }
+            for (int a = 1; a < nj; ++a) {
+                int key = js[a], c = a - 1;
+                while (c >= 0 && js[c] > key) { js[c + 1] = js[c]; --c; }
+                js[c + 1] = key;
+            }
+            bool near_here = false;
+            for (int a = 0; a < nj; ++a) {
+                int j = js[a];
+                f = caf_then(f, (j == r.n - 1 && occ) ? fO : fE);
+                if (j == r.n - 2 && (info & RI_NEAR)) near_here = true;
+            }
+            if (near_here) f = caf_then(f, fN);
+            has = nj > 0;
+        }
+        if (__ballot(has) == 0ull) continue;
+        for (int off = 1; off < 64; off <<= 1) {
+            Caf g;
+            g.a = __shfl_down(f.a, off, 64); g.lo = __shfl_down(f.lo, off, 64); g.hi = __shfl_down(f.hi, off, 64);
+            if ((lane & (2 * off - 1)) == 0) f = caf_then(f, g);
+        }
+        val = caf_apply(f, val);        // lane 0 holds the fold of the whole chunk
+        val = __shfl(val, 0, 64);
+    }
+    return val;
+}
+
+__global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   // 2 workgroups per CU
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int NB = mu_nb(v.B);
+    MuLds s;
+    s.cnt = reinterpret_cast<uint32_t*>(smem);
+    s.flag = s.cnt + WIN * WIN / 2;
+    const int CH_CAP = mu_chunk_cap(v.B);
+    const int BPAD = (v.B + 3) & ~3;
+    s.fpre = reinterpret_cast<uint16_t*>(s.flag + WIN * WIN / 32);
+    s.bev = s.fpre + WIN * WIN / 32;
+    s.bcell = s.bev + EV_TOT;
+    s.chunk = s.bcell + NB;
+    s.lutx = reinterpret_cast<int16_t*>(s.chunk + CH_CAP);
+    s.luty = s.lutx + (WIN + 8);
+    s.r_end = reinterpret_cast<int32_t*>(s.luty + (WIN + 8));
+    s.seg_lo = reinterpret_cast<int16_t*>(s.r_end + BPAD);
+    s.seg_hi = s.seg_lo + BPAD;
+    s.r_info = reinterpret_cast<uint8_t*>(s.seg_hi + BPAD);
+
+    __shared__ double s_c, s_s, s_px, s_py;
+    __shared__ int s_x0, s_y0, s_skip;
+    __shared__ int s_need[49], s_tab[49];
+    __shared__ int s_fan[4];                       // ray fan bounding box: gx min, gx max, gy min, gy max
+    __shared__ int s_nflag, s_bb[4], s_written, s_nslow, s_nbig, s_nchunk, s_wsum[MU_BLOCK / 64], s_tot_written, s_tot_slow;
+    static_assert(WIN * WIN / 32 == MU_BLOCK, "one flag word per thread");
+    __shared__ unsigned long long s_cells;
+
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int LL = v.L * v.L;
+    const int KW = (v.dim + WIN - 1) / WIN;        // windows per tile axis
+    int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+
+#ifdef RBPF_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#endif
+    // =============================================== setup ===============================================
+    if (tid == 0) {
+        double px = v.upd_pose[p], py = v.upd_pose[v.P + p], th = v.upd_pose[2 * v.P + p];
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        s_c = cs; s_s = sn; s_px = px; s_py = py;
+        int x0 = trunc_to_int(px / v.cs), y0 = trunc_to_int(py / v.cs);      // hybridmap.py:102
+        s_x0 = x0; s_y0 = y0;
+        // hybridmap.py:98-100: no tile holds the robot position -> the update is a no-op
+        int lx, ly;
+        bool ok = tile_of_coord(px, v.tile_len, v.R, lx) && tile_of_coord(py, v.tile_len, v.R, ly);
+        if (ok) ok = tab[(lx + v.R) * v.L + (ly + v.R)] >= 0;
+        const int reach = v.reach;                 // the whole fan must stay inside the LUT (lattice radius)
+        bool in_lut = lut_valid_g(v, x0 - reach) && lut_valid_g(v, x0 + reach) &&
+                      lut_valid_g(v, y0 - reach) && lut_valid_g(v, y0 + reach);
+        if (ok && !in_lut) { atomicCAS(v.err, 0, RBPF_ERANGE); ok = false; }
+        s_skip = ok ? 0 : 1;
+        s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
+        s_cells = 0; s_tot_written = 0; s_tot_slow = 0;
+    }
+    for (int i = tid; i < LL; i += MU_BLOCK) { s_need[i] = 0; s_tab[i] = tab[i]; }
+    __syncthreads();
+    if (s_skip) return;
+
+    const int x0 = s_x0, y0 = s_y0;
+    const int a0 = lut_lat(lut_at(v, x0)), b0 = lut_lat(lut_at(v, y0));
+    {
+        unsigned long long my_cells = 0;
+        int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
+        for (int b = tid; b < v.B; b += MU_BLOCK) {
+            const double x = v.bx[b], y = v.by[b];
+            const int bf = v.bflags[b];
+            double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
+            double gy = (s_s * x + s_c * y) + s_py;
+            int x1 = trunc_to_int(gx / v.cs), y1 = trunc_to_int(gy / v.cs);        // hybridmap.py:106
+            if (bf & BF_LONG) {                                                    // hybridmap.py:107-113
+                double sc = v.bscale[b];
+                x1 = trunc_to_int((double)x0 + sc * (double)(x1 - x0));
+                y1 = trunc_to_int((double)y0 + sc * (double)(y1 - y0));
+            }
+            int ddx = x1 - x0, ddy = y1 - y0;
+            if (ddx < -v.reach || ddx > v.reach || ddy < -v.reach || ddy > v.reach) {
+                atomicCAS(v.err, 0, RBPF_ERANGE);
+                ddx = 0; ddy = -1; x1 = x0; y1 = y0 - 1;                           // degenerate: no points
+            }
+            s.r_end[b] = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
+            Ray r = ray_make(x0, y0, x1, y1);
+            int info = 0;
+            if (r.n > 0) {
+                info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
+                my_cells += (unsigned long long)r.n;
+                fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
+                if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
+                    int nx, ny;
+                    ray_point(r, r.n - 2, nx, ny);
+                    if (same_tile(v, nx, ny, x1, y1)) info |= RI_NEAR;
+                    info |= ((nx - x1 + 1) & 3) << 3;
+                    info |= ((ny - y1 + 1) & 3) << 5;
+                }
+                // tiles entered by this ray (staircase start -> [corner] -> end)
+                const int a1 = lut_lat(lut_at(v, x1)), b1 = lut_lat(lut_at(v, y1));
+                s_need[a0 * v.L + b0] = 1;
+                if (a1 != a0 || b1 != b0) {
+                    s_need[a1 * v.L + b1] = 1;
+                    if (a1 != a0 && b1 != b0) {
+                        // first global index on the far side of each boundary, in the ray's direction
+                        int gxb = r.sx > 0 ? v.gwin[a1 * (KW + 1)] : v.gwin[a0 * (KW + 1)] - 1;
+                        int gyb = r.sy > 0 ? v.gwin[b1 * (KW + 1)] : v.gwin[b0 * (KW + 1)] - 1;
+                        int ox = gxb - x0; ox = ox < 0 ? -ox : ox;
+                        int oy = gyb - y0; oy = oy < 0 ? -oy : oy;
+                        int jx = r.steep ? first_j_minor_ge(r, ox) : ox;
+                        int jy = r.steep ? oy : first_j_minor_ge(r, oy);
+                        if (jx < jy) s_need[a1 * v.L + b0] = 1;
+                        else if (jy < jx) s_need[a0 * v.L + b1] = 1;
+                    }
+                }
+            }
+            s.r_info[b] = (uint8_t)info;
+        }
+        if (my_cells) {
+            atomicAdd(&s_cells, my_cells);
+            atomicMin(&s_fan[0], fx0); atomicMax(&s_fan[1], fx1);
+            atomicMin(&s_fan[2], fy0); atomicMax(&s_fan[3], fy1);
+        }
+    }
+    __syncthreads();
+    // allocate missing tiles (free tiles are kept zero-filled)
+    if (tid < LL && s_need[tid] && s_tab[tid] < 0) {
+        int idx = atomicSub(v.free_top, 1) - 1;
+        if (idx < 0) {
+            atomicAdd(v.free_top, 1);
+            atomicCAS(v.err, 0, RBPF_ENOMEM);
+            s_need[tid] = 0;
+        } else {
+            int t = v.free_stack[idx];
+            s_tab[tid] = t;
+            tab[tid] = t;
+            v.tile_bbox[4 * t + 0] = INT_MAX; v.tile_bbox[4 * t + 1] = -1;
+            v.tile_bbox[4 * t + 2] = INT_MAX; v.tile_bbox[4 * t + 3] = -1;
+        }
+    }
+    __syncthreads();
+
+    STAMP(0);
+    // ============================================ window loop ==============================================
+    const size_t tile_cells = (size_t)v.dim * v.dim;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int t = 0; t < LL; ++t) {
+        if (!s_need[t]) continue;                          // uniform over the workgroup
+        const int la = t / v.L, lb = t % v.L;
+        const int tile = s_tab[t];
+        const int* gwx = v.gwin + la * (KW + 1);
+        const int* gwy = v.gwin + lb * (KW + 1);
+        const int lox = max(gwx[0], s_fan[0]), hix = min(gwx[KW] - 1, s_fan[1]);
+        const int loy = max(gwy[0], s_fan[2]), hiy = min(gwy[KW] - 1, s_fan[3]);
+        if (lox > hix || loy > hiy) continue;
+        const int wx_lo = lut_cidx(lut_at(v, lox)) / WIN, wx_hi = lut_cidx(lut_at(v, hix)) / WIN;
+        const int wy_lo = lut_cidx(lut_at(v, loy)) / WIN, wy_hi = lut_cidx(lut_at(v, hiy)) / WIN;
+        int8_t* __restrict__ tile_base = v.pool + (size_t)tile * tile_cells;
+        int tile_bb[4] = {INT_MAX, -1, INT_MAX, -1};       // thread 0 accumulates the tile's written box
+
+        for (int wxi = wx_lo; wxi <= wx_hi; ++wxi)
+        for (int wyi = wy_lo; wyi <= wy_hi; ++wyi) {
+            const int wx0 = wxi * WIN, wy0 = wyi * WIN;
+            const int gxa = gwx[wxi], gxb = gwx[wxi + 1], gya = gwy[wyi], gyb = gwy[wyi + 1];   // [gxa,gxb) x [gya,gyb)
+            const int nx_ = gxb - gxa, ny_ = gyb - gya;
+            __syncthreads();                               // previous window fully done with LDS
+            // ---- phase 0: clear the counters, local index maps ----------------------------------------------------
+            {
+                uint4* c4 = reinterpret_cast<uint4*>(s.cnt);
+                for (int i = tid; i < WIN * WIN / 8; i += MU_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
+                for (int i = tid; i < WIN * WIN / 32; i += MU_BLOCK) s.flag[i] = 0;
+                for (int i = tid; i < nx_ && i < WIN + 8; i += MU_BLOCK) s.lutx[i] = (int16_t)(lut_cidx(lut_at(v, gxa + i)) - wx0);
+                for (int i = tid; i < ny_ && i < WIN + 8; i += MU_BLOCK) s.luty[i] = (int16_t)(lut_cidx(lut_at(v, gya + i)) - wy0);
+                if (tid == 0) {
+                    s_nflag = 0; s_written = 0; s_nslow = 0; s_nbig = 0; s_nchunk = 0;
+                    s_bb[0] = INT_MAX; s_bb[1] = -1; s_bb[2] = INT_MAX; s_bb[3] = -1;
+                }
+            }
+            __syncthreads();
+            STAMP(1);
+
+            // ---- phase 1: flag the cells that receive an "occupied" or "nearby" hit; clip every ray to the window ----
+            for (int b = tid; b < v.B; b += MU_BLOCK) {
+                const int info = s.r_info[b];
+                int jlo = 1, jhi = 0;
+                if (info & RI_VALID) {
+                    int x1, y1;
+                    unpack_end(s.r_end[b], x0, y0, x1, y1);
+                    if ((info & RI_OCC)) {                                              // hybridmap.py:113,137
+                        if (x1 >= gxa && x1 < gxb && y1 >= gya && y1 < gyb) {
+                            int c = s.lutx[x1 - gxa] * WIN + s.luty[y1 - gya];
+                            atomicOr(&s.flag[c >> 5], 1u << (c & 31));
+                            atomicOr(&s.cnt[c >> 1], 0x8000u << ((c & 1) * 16));
+                        }
+                        if (info & RI_NEAR) {                                         // hybridmap.py:139-142
+                            int nx = x1 + ((info >> 3) & 3) - 1, ny = y1 + ((info >> 5) & 3) - 1;
+                            if (nx >= gxa && nx < gxb && ny >= gya && ny < gyb) {
+                                int c = s.lutx[nx - gxa] * WIN + s.luty[ny - gya];
+                                atomicOr(&s.flag[c >> 5], 1u << (c & 31));
+                                atomicOr(&s.cnt[c >> 1], 0x8000u << ((c & 1) * 16));
+                            }
+                        }
+                    }
+                    // clip j to the window: major axis by interval arithmetic, minor axis by the closed form
+                    if (!(max(x0, x1) < gxa || min(x0, x1) >= gxb || max(y0, y1) < gya || min(y0, y1) >= gyb)) {
+                        Ray r = ray_make(x0, y0, x1, y1);
+                        int ma = r.steep ? gya : gxa, mb = r.steep ? gyb : gxb;      // major bounds [ma, mb)
+                        int na = r.steep ? gxa : gya, nb = r.steep ? gxb : gyb;      // minor bounds [na, nb)
+                        int m0 = r.steep ? y0 : x0, n0 = r.steep ? x0 : y0;
+                        int smaj = r.steep ? r.sy : r.sx, smin = r.steep ? r.sx : r.sy;
+                        jlo = smaj > 0 ? ma - m0 : m0 - (mb - 1);
+                        jhi = smaj > 0 ? (mb - 1) - m0 : m0 - ma;
+                        int olo = smin > 0 ? na - n0 : n0 - (nb - 1);                // minor offset range [olo, ohi]
+                        int ohi = smin > 0 ? (nb - 1) - n0 : n0 - na;
+                        jlo = max(jlo, 0); jhi = min(jhi, r.n - 1);
+                        if (ohi < 0) jhi = -1;
+                        else if (r.dmin == 0) { if (olo > 0) jhi = -1; }
+                        else {
+                            if (olo > 0) jlo = max(jlo, first_j_minor_ge(r, olo));
+                            jhi = min(jhi, last_j_minor_le(r, ohi));
+                        }
+                    }
+                }
+                // chunks of up to CHUNK steps, one table entry each: (beam << 3) | chunk index
+                if (jlo <= jhi) {
+                    s.seg_lo[b] = (int16_t)jlo; s.seg_hi[b] = (int16_t)jhi;
+                    int nch = (jhi - jlo) / CHUNK + 1;
+                    int base = atomicAdd(&s_nchunk, nch);
+                    for (int k = 0; k < nch; ++k) if (base + k < CH_CAP) s.chunk[base + k] = (uint16_t)((b << 3) | k);
+                }
+            }
+            __syncthreads();
+            // rank of every flagged cell among the window's flagged cells = its bucket id (cell order)
+            {
+                const int w = tid;                          // one flag word per thread (WIN*WIN/32 == MU_BLOCK)
+                const uint32_t bits = s.flag[w];
+                int pc = __popc(bits), incl = pc;
+                for (int off = 1; off < 64; off <<= 1) { int n = __shfl_up(incl, off, 64); if (lane >= off) incl += n; }
+                if (lane == 63) s_wsum[wave] = incl;
+                __syncthreads();
+                int wbase = 0;
+                for (int k = 0; k < wave; ++k) wbase += s_wsum[k];
+                const int excl = wbase + incl - pc;
+                s.fpre[w] = (uint16_t)excl;
+                if (tid == MU_BLOCK - 1) s_nflag = excl + pc;
+                uint32_t bb = bits; int id = excl;
+                while (bb) { int bit = __ffs(bb) - 1; bb &= bb - 1; if (id < NB) s.bcell[id] = (uint16_t)(w * 32 + bit); ++id; }
+            }
+            __syncthreads();
+            // event slots are shared out evenly: few flagged cells (a near wall under dense beams) get deep buckets
+            const int nflag = s_nflag;
+            const int cap = min(64, max(4, EV_TOT / max(nflag, 1)));
+            const int nbk = min(min(nflag, NB), EV_TOT / cap);
+            STAMP(2);
+
+            // ---- phase 2: walk the clipped rays, CHUNK steps per work item ------------------------------------------
+            {
+                const int nchunk = min(s_nchunk, CH_CAP);
+                if (s_nchunk > CH_CAP && tid == 0) atomicCAS(v.err, 0, RBPF_ENOMEM);   // cannot happen: B*5 entries
+                for (int q = tid; q < nchunk; q += MU_BLOCK) {
+                    const int desc = s.chunk[q];
+                    const int b = desc >> 3;
+                    const int info = s.r_info[b];
+                    int x1, y1;
+                    unpack_end(s.r_end[b], x0, y0, x1, y1);
+                    const Ray r = ray_make(x0, y0, x1, y1);
+                    const int jlo = s.seg_lo[b] + (desc & 7) * CHUNK;
+                    const int jhi = min((int)s.seg_hi[b], jlo + CHUNK - 1);
+                    const int m0 = r.steep ? y0 : x0, n0 = r.steep ? x0 : y0;
+                    const int smaj = r.steep ? r.sy : r.sx, smin = r.steep ? r.sx : r.sy;
+                    const bool occ = info & RI_OCC;
+                    const bool near_ok = info & RI_NEAR;
+                    int m = ray_minor_at(r, jlo);
+                    int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;   // hybridmap.py:289-300 invariant
+                    for (int j = jlo; j <= jhi; ++j) {
+                        const int maj = m0 + smaj * j, mnr = n0 + smin * m;
+                        const int ix = (r.steep ? mnr : maj) - gxa, iy = (r.steep ? maj : mnr) - gya;
+                        if (D >= 0) { ++m; D -= 2 * r.dmaj; }
+                        D += 2 * r.dmin;
+                        if ((unsigned)ix >= (unsigned)nx_ || (unsigned)iy >= (unsigned)ny_) continue;
+                        const int c = s.lutx[ix] * WIN + s.luty[iy];
+                        const int sh = (c & 1) * 16;
+                        const uint32_t old = atomicAdd(&s.cnt[c >> 1], 1u << sh);
+                        const uint32_t h = (old >> sh) & 0xFFFFu;
+                        if (h & 0x8000u) {                  // flagged: the counter value is the slot in the cell's bucket
+                            const int id = s.fpre[c >> 5] + __popc(s.flag[c >> 5] & ((1u << (c & 31)) - 1u));
+                            const int rem = r.n - 1 - j;
+                            const int rank = (rem == 0) ? (occ ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+                            int pos = (int)(h & 0x7FFFu);
+                            if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | rank);
+                            if (near_ok && rem == 1) {
+                                const uint32_t old2 = atomicAdd(&s.cnt[c >> 1], 1u << sh);
+                                pos = (int)((old2 >> sh) & 0x7FFFu);
+                                if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | EV_NEAR);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            STAMP(3);
+
+            // ---- phase 3a: cells that only received "empty" hits: v = max(v + n*emp, min) ---------------------------
+            int my_written = 0;
+            int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
+            {
+                constexpr int PER = 4;                                  // 32-bit words (4 cells) in flight per thread
+                for (int i0 = 0; i0 < WIN * WIN / 4 / MU_BLOCK; i0 += PER) {
+                uint32_t wd[PER], n01[PER], n23[PER];
+                uint32_t* gp[PER];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {                         // all loads first: the read-modify-write is latency-bound
+                    const int q = tid + (i0 + i) * MU_BLOCK;
+                    const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
+                    uint32_t w0 = s.cnt[(lx * WIN + ly) >> 1], w1 = s.cnt[((lx * WIN + ly) >> 1) + 1];
+                    if (w0 & 0x00008000u) w0 &= 0xFFFF0000u;            // flagged cells are replayed in phase 3b
+                    if (w0 & 0x80000000u) w0 &= 0x0000FFFFu;
+                    if (w1 & 0x00008000u) w1 &= 0xFFFF0000u;
+                    if (w1 & 0x80000000u) w1 &= 0x0000FFFFu;
+                    n01[i] = w0; n23[i] = w1;
+                    gp[i] = reinterpret_cast<uint32_t*>(tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly));
+                    wd[i] = (w0 | w1) ? *gp[i] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    if (!(n01[i] | n23[i])) continue;
+                    const int q = tid + (i0 + i) * MU_BLOCK;
+                    const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
+                    const uint32_t n[4] = {n01[i] & 0xFFFFu, n01[i] >> 16, n23[i] & 0xFFFFu, n23[i] >> 16};
+                    uint32_t word = wd[i];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (n[k]) {
+                            int val = (int)(int8_t)((word >> (8 * k)) & 0xFFu);
+                            val = cell_emp_n(val, (int)n[k], v.cc);
+                            word = (word & ~(0xFFu << (8 * k))) | (((uint32_t)val & 0xFFu) << (8 * k));
+                            ++my_written;
+                            by0 = min(by0, wy0 + ly + k); by1 = max(by1, wy0 + ly + k);
+                        }
+                    }
+                    *gp[i] = word;
+                    bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+                }
+                }
+            }
+            __syncthreads();   // flagged cells share 32-bit words with phase-3a cells: finish 3a first
+            STAMP(4);
+
+            // ---- phase 3b: flagged cells, ordered replay from their buckets ------------------------------------------
+            // (the chunk table is dead now: its memory holds the two work lists of this phase)
+            uint16_t* bigc = s.chunk;                       // buckets of 9..cap events: folded by one wave each
+            uint16_t* slowc = s.chunk + NB;                 // bucket overflow / no bucket: exact membership scan
+            for (int id = tid; id < min(nflag, NB); id += MU_BLOCK) {
+                const int c = s.bcell[id];
+                const int m = id < nbk ? (int)(cnt16_get(s.cnt, c) & 0x7FFFu) : INT_MAX;
+                if (m > cap) { slowc[atomicAdd(&s_nslow, 1)] = (uint16_t)c; continue; }
+                if (m > SMALL_BUCKET) { bigc[atomicAdd(&s_nbig, 1)] = (uint16_t)id; continue; }
+                const int lx = c / WIN, ly = c % WIN;
+                int8_t* gpc = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
+                int val = *gpc;
+                uint32_t ev[SMALL_BUCKET];
+#pragma unroll
+                for (int e = 0; e < SMALL_BUCKET; ++e) ev[e] = e < m ? (uint32_t)s.bev[id * cap + e] : 0xFFFFFFFFu;
+                // replay in ascending (beam, rank): selection by repeated minimum over registers
+                for (int k = 0; k < m; ++k) {
+                    uint32_t best = 0xFFFFFFFFu; int be = 0;
+#pragma unroll
+                    for (int e = 0; e < SMALL_BUCKET; ++e) if (ev[e] < best) { best = ev[e]; be = e; }
+#pragma unroll
+                    for (int e = 0; e < SMALL_BUCKET; ++e) if (e == be) ev[e] = 0xFFFFFFFFu;
+                    val = cell_apply_rank(val, (int)(best & 7u), v.cc);
+                }
+                *gpc = (int8_t)val;
+                ++my_written;
+                bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+                by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
+            }
+            if (nflag > NB) {   // more flagged cells than bucket ids: the rest is replayed by membership scan
+                for (int id = NB + tid; id < nflag; id += MU_BLOCK) {
+                    // the id-th flagged cell in cell order: find its word by the prefix counts
+                    int lo = 0, hi = WIN * WIN / 32 - 1;
+                    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if ((int)s.fpre[mid] <= id) lo = mid; else hi = mid - 1; }
+                    uint32_t bb = s.flag[lo]; int k = id - s.fpre[lo];
+                    while (k--) bb &= bb - 1;
+                    const int c = lo * 32 + __ffs(bb) - 1;
+                    int pos = atomicAdd(&s_nslow, 1);
+                    if (pos < CH_CAP - NB) slowc[pos] = (uint16_t)c; else atomicCAS(v.err, 0, RBPF_ENOMEM);
+                }
+            }
+            __syncthreads();
+            // ---- phase 3c: deep buckets and bucket-less cells, one wave per cell -----------------------------------------
+            {
+                const int nbig = s_nbig;
+                for (int k = wave; k < nbig; k += MU_BLOCK / 64) {
+                    const int id = bigc[k];
+                    const int c = s.bcell[id];
+                    const int m = (int)(cnt16_get(s.cnt, c) & 0x7FFFu);            // 9..64 events, one per lane
+                    const uint32_t key = lane < m ? (uint32_t)s.bev[id * cap + lane] : 0xFFFFFFFFu;
+                    int rank = 0;
+                    for (int e = 0; e < m; ++e) {
+                        const uint32_t ke = __shfl(key, e, 64);
+                        rank += (ke < key) || (ke == key && e < lane);
+                    }
+                    // move every event to the lane of its rank, then fold the clamped adds in lane order
+                    const uint32_t sorted = (uint32_t)__builtin_amdgcn_ds_permute((lane < m ? rank : lane) << 2, (int)key);
+                    const int BIG = 1000000;
+                    Caf f = {0, -BIG, BIG};
+                    if (lane < m) {
+                        const int rk = (int)(sorted & 7u);
+                        f = rk == EV_OCC ? Caf{v.cc.occ, -BIG, v.cc.vmax} : rk == EV_NEAR ? Caf{v.cc.nearby, -BIG, v.cc.vmax}
+                                                                                        : Caf{v.cc.emp, v.cc.vmin, BIG};
+                    }
+                    for (int off = 1; off < 64; off <<= 1) {
+                        Caf g;
+                        g.a = __shfl_down(f.a, off, 64); g.lo = __shfl_down(f.lo, off, 64); g.hi = __shfl_down(f.hi, off, 64);
+                        if ((lane & (2 * off - 1)) == 0) f = caf_then(f, g);
+                    }
+                    if (lane == 0) {
+                        const int lx = c / WIN, ly = c % WIN;
+                        int8_t* gpc = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
+                        *gpc = (int8_t)caf_apply(f, (int)*gpc);
+                        ++my_written;
+                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+                        by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
+                    }
+                }
+                const int nslow = min(s_nslow, CH_CAP - NB);
+                for (int k = wave; k < nslow; k += MU_BLOCK / 64) {
+                    const int c = slowc[k];
+                    const int lx = c / WIN, ly = c % WIN;
+                    int8_t* gpc = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
+                    int gxc[4], gyc[4], ngx = 0, ngy = 0;
+                    for (int i = 0; i < nx_ && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
+                    for (int i = 0; i < ny_ && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
+                    int val = replay_cell_wave(v, s, x0, y0, gxc, ngx, gyc, ngy, (int)*gpc, lane);
+                    if (lane == 0) {
+                        *gpc = (int8_t)val;
+                        ++my_written;
+                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+                        by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
+                    }
+                }
+                if (tid == 0 && nslow) s_tot_slow += nslow;
+            }
+            STAMP(5);
+            // ---- phase 4: bounding box of written cells (bounds resample copies), counters ---------------------------
+            if (my_written) {
+                atomicAdd(&s_written, my_written);
+                atomicMin(&s_bb[0], bx0); atomicMax(&s_bb[1], bx1);
+                atomicMin(&s_bb[2], by0); atomicMax(&s_bb[3], by1);
+            }
+            __syncthreads();
+            STAMP(6);
+            if (tid == 0 && s_written) {
+                s_tot_written += s_written;
+                tile_bb[0] = min(tile_bb[0], s_bb[0]); tile_bb[1] = max(tile_bb[1], s_bb[1]);
+                tile_bb[2] = min(tile_bb[2], s_bb[2]); tile_bb[3] = max(tile_bb[3], s_bb[3]);
+            }
+        }
+        if (tid == 0 && tile_bb[1] >= 0) {          // this workgroup is the tile's only writer
+            v.tile_bbox[4 * tile + 0] = min(v.tile_bbox[4 * tile + 0], tile_bb[0]);
+            v.tile_bbox[4 * tile + 1] = max(v.tile_bbox[4 * tile + 1], tile_bb[1]);
+            v.tile_bbox[4 * tile + 2] = min(v.tile_bbox[4 * tile + 2], tile_bb[2]);
+            v.tile_bbox[4 * tile + 3] = max(v.tile_bbox[4 * tile + 3], tile_bb[3]);
+        }
+    }
+    if (tid == 0) {
+        if (s_cells) atomicAdd(&v.stats[ST_RAY_CELLS], s_cells);
+        if (s_tot_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_tot_written);
+        if (s_tot_slow) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)s_tot_slow);
+#ifdef RBPF_STAMPS
+        for (int k = 0; k < 7; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+#endif
+    }
+}
+
+void launch_map_update_fused(const DevView& v, hipStream_t s) {
+    size_t lds = raycast_lds_bytes(v.B);
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {   // more than the default 64 KiB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(map_update_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v);
+}
+
+}  // namespace rbpf

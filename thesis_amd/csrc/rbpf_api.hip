@@ -134,7 +134,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     v.inv_quantum = fabs(inv - round(inv)) < 1e-9 ? round(inv) : 0.0;
     v.cc = cc;
     v.w_min_range = c.weight_min_range; v.w_max_range = c.weight_max_range;
-    v.items_cap = raycast_items_cap(c);
+    v.items_cap = 0;
     v.reach = (int)(c.max_ray_m / c.cell_size) + 3;
 
     // ---- global-index LUT (hybridmap.py:123,136 + gridmap.py:93) -------------------------------
@@ -169,6 +169,18 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         const size_t P = v.P, LL = (size_t)v.L * v.L, cells = (size_t)dim * dim;
         uint32_t* d_lut; ALLOC(h, d_lut, h->h_lut.size()); v.lut = d_lut;
         HIP_TRY(h, hipMemcpy(d_lut, h->h_lut.data(), h->h_lut.size() * 4, hipMemcpyHostToDevice));
+        {   // inverse LUT: first global index of every 128-cell window of every lattice row
+            const int KW = (dim + WIN - 1) / WIN;
+            std::vector<int32_t> gw((size_t)v.L * (KW + 1));
+            for (int a = 0; a < v.L; ++a)
+                for (int k = 0; k <= KW; ++k) {
+                    uint32_t key = k < KW ? (((uint32_t)a << 16) | (uint32_t)(k * WIN)) : ((uint32_t)(a + 1) << 16);
+                    auto it = std::lower_bound(h->h_lut.begin(), h->h_lut.end(), key);
+                    gw[(size_t)a * (KW + 1) + k] = v.g_min + (int32_t)(it - h->h_lut.begin());
+                }
+            int32_t* d_gw; ALLOC(h, d_gw, gw.size()); v.gwin = d_gw;
+            HIP_TRY(h, hipMemcpy(d_gw, gw.data(), gw.size() * 4, hipMemcpyHostToDevice));
+        }
         ALLOC(h, v.px, P); ALLOC(h, v.py, P); ALLOC(h, v.pth, P); ALLOC(h, v.cov, 9 * P); ALLOC(h, v.weight, P);
         ALLOC(h, v.slot, P); ALLOC(h, v.global_id, P);
         ALLOC(h, v.tile_tab, P * LL); ALLOC(h, v.pool, (size_t)v.pool_tiles * cells);
@@ -178,12 +190,12 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, dtmp, (size_t)c.max_beams); v.by = dtmp;
         ALLOC(h, dtmp, (size_t)c.max_beams); v.bscale = dtmp;
         ALLOC(h, btmp, (size_t)c.max_beams); v.bflags = btmp;
-        ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.ray_end, P * (size_t)c.max_beams); ALLOC(h, v.ray_start, 2 * P);
-        ALLOC(h, v.items, P * (size_t)v.items_cap * 4); ALLOC(h, v.n_items, 2);
-        ALLOC(h, v.stats, 8); ALLOC(h, v.err, 1);
+        ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.n_items, 2);
+        ALLOC(h, v.stats, 16); ALLOC(h, v.err, 1);
         ALLOC(h, v.msel_x, (size_t)c.max_beams); ALLOC(h, v.msel_y, (size_t)c.max_beams);
         ALLOC(h, v.asel_x, (size_t)c.max_beams); ALLOC(h, v.asel_y, (size_t)c.max_beams);
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
+        if (raycast_lds_bytes(c.max_beams) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
         match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
         h->mlds = match_lds_bytes(h->mN, c.max_beams, match_max_coarse(h->mncr, 0.7, h->mmcs));
         if (h->mlds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this cell_size");
@@ -198,7 +210,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemset(v.pool, 0, (size_t)v.pool_tiles * cells));
         HIP_TRY(h, hipMemset(v.px, 0, P * 8)); HIP_TRY(h, hipMemset(v.py, 0, P * 8)); HIP_TRY(h, hipMemset(v.pth, 0, P * 8));
         HIP_TRY(h, hipMemset(v.cov, 0, 9 * P * 8));
-        HIP_TRY(h, hipMemset(v.stats, 0, 64)); HIP_TRY(h, hipMemset(v.err, 0, 4)); HIP_TRY(h, hipMemset(v.n_items, 0, 8));
+        HIP_TRY(h, hipMemset(v.stats, 0, 128)); HIP_TRY(h, hipMemset(v.err, 0, 4)); HIP_TRY(h, hipMemset(v.n_items, 0, 8));
         // robot.py:20-28 / hybridmap.py:70: weight 1.0, one empty tile centred (0,0) per particle
         std::vector<double> w(P, 1.0);
         HIP_TRY(h, hipMemcpy(v.weight, w.data(), P * 8, hipMemcpyHostToDevice));
@@ -258,7 +270,7 @@ int rbpf_set_profiling(rbpf_handle* h, int on) {
     if (!h) return RBPF_EINVAL;
     h->profiling = on != 0;
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) h->ring_n[k] = 0;
-    HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, 8 * sizeof(unsigned long long), h->stream));   // counters restart
+    HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, 16 * sizeof(unsigned long long), h->stream));   // counters restart
     return RBPF_OK;
 }
 
@@ -281,7 +293,7 @@ int rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t ca
 
 int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     if (!h || !out) return RBPF_EINVAL;
-    unsigned long long st[8];
+    unsigned long long st[16];
     int32_t top = 0;
     HIP_TRY(h, hipMemcpyAsync(st, h->v.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&top, h->v.free_top, 4, hipMemcpyDeviceToHost, h->stream));
@@ -292,6 +304,7 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.cells_gathered = st[ST_GATHERS]; c.slow_cells = st[ST_SLOW_CELLS];
     c.resample_copies = st[ST_COPIES]; c.bytes_copied = st[ST_COPY_BYTES];
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
+    for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];      // phase cycle sums of a -DRBPF_STAMPS diagnostic build
     if (h->profiling) {
         double* dst[4] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match};
         for (int k = 0; k < 4; ++k) {
@@ -392,11 +405,8 @@ int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs
 // ---- a5 test entry --------------------------------------------------------------------------------------
 static int run_map_update(rbpf_handle* h) {
     DevView& v = h->v;
-    h->prof_begin(4);
-    launch_ray_setup(v, h->stream);
-    h->prof_end(4);
     h->prof_begin(0);
-    launch_raycast_windows(v, h->stream);
+    launch_map_update_fused(v, h->stream);
     h->prof_end(0);
     HIP_TRY(h, hipGetLastError());
     h->scan_updates++;

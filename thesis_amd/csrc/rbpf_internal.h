@@ -30,6 +30,7 @@ struct DevView {
     double w_min_range, w_max_range;
     // LUT over global cell indices g in [g_min, g_min + n_lut)
     const uint32_t* lut; int g_min, n_lut;
+    const int32_t* gwin;               // [L][KW+1] first global index of each 128-cell window of a lattice row (KW = ceil(dim/WIN)); [KW] = next tile
     // particle state, SoA, logical particle order
     double *px, *py, *pth;             // [P]
     double *cov;                       // [9][P]
@@ -104,8 +105,7 @@ namespace rbpf {
 // kernel launchers (one translation unit per kernel family)
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
-void launch_ray_setup(const DevView& v, hipStream_t s);
-void launch_raycast_windows(const DevView& v, hipStream_t s);
+void launch_map_update_fused(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
 void launch_imu_update(const DevView& v, int model, double d0, double d1, double d2, double dt_ticks,
@@ -125,5 +125,4 @@ void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const
                          const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
                          double d0, int ncr, int cap_sel, size_t lds, hipStream_t s);
 size_t raycast_lds_bytes(int B);
-int raycast_items_cap(const rbpf_config& cfg);
 }  // namespace rbpf

@@ -106,7 +106,9 @@ class ParticleEngine:
     def counters(self) -> Dict[str, float]:
         c = RbpfCounters()
         self._check(self._lib.rbpf_get_counters(self._h, C.byref(c)))
-        return {k: getattr(c, k) for k, _ in RbpfCounters._fields_ if k != "reserved"}
+        out = {k: getattr(c, k) for k, _ in RbpfCounters._fields_ if k != "reserved"}
+        out["stamps"] = list(c.reserved)
+        return out
 
     # -- a1 ------------------------------------------------------------------------------------------
     def set_scan(self, ranges, angles):
