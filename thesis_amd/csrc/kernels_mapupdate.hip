@@ -37,11 +37,15 @@ namespace rbpf {
 #define STAMP(k) do { } while (0)
 #endif
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every
+// outstanding global load AND store; inside the window loop no thread reads or overwrites a global cell another
+// thread of the workgroup wrote in the same kernel, so the HBM read-modify-writes may stay in flight across it.
+#define BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 static const int MU_BLOCK = 512;       // 8 waves per particle
 static const int NB_MAX = 2304;        // bucket ids per window
 static const int EV_TOT = 6144;        // event slots per window
 static const int CHUNK = 32;           // ray steps per work item of the walk
-static const int SMALL_BUCKET = 8;     // buckets up to this size are replayed by one lane from registers
 
 __host__ __device__ inline int mu_nb(int B) { int nb = 2 * B; return nb < NB_MAX ? nb : NB_MAX; }
 // chunk table entries: every ray has at most ceil((WIN + 2) / CHUNK) = 5 chunks in a window; the same memory later
@@ -107,6 +111,33 @@ __device__ __forceinline__ Caf caf_then(Caf f, Caf g) {          // g after f
     return r;
 }
 __device__ __forceinline__ int caf_apply(Caf f, int x) { int t = x + f.a; t = t < f.lo ? f.lo : t; return t > f.hi ? f.hi : t; }
+
+// One lane replays a bucket of up to N events: bitonic sorting network on registers (padded with 0xFFFF), then the
+// clamped adds in ascending (beam, rank) order.
+template <int N>
+__device__ __forceinline__ int replay_sorted(const uint16_t* __restrict__ evp, int m, int val, const CellConsts& cc) {
+    uint32_t ev[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) ev[e] = e < m ? (uint32_t)evp[e] : 0xFFFFu;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = ev[i], b = ev[l];
+                    const bool up = (i & k) == 0;
+                    ev[i] = up ? min(a, b) : max(a, b);
+                    ev[l] = up ? max(a, b) : min(a, b);
+                }
+            }
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+        if (e < m) val = cell_apply_rank(val, (int)(ev[e] & 7u), cc);
+    return val;
+}
 
 __device__ int replay_cell_wave(const DevView& v, const MuLds& s, int x0, int y0, const int* gxc, int ngx,
                                 const int* gyc, int ngy, int val, int lane) {
@@ -300,6 +331,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     // ============================================ window loop ==============================================
     const size_t tile_cells = (size_t)v.dim * v.dim;
     const int lane = tid & 63, wave = tid >> 6;
+    const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);     // hits that saturate any cell: 20
     for (int t = 0; t < LL; ++t) {
         if (!s_need[t]) continue;                          // uniform over the workgroup
         const int la = t / v.L, lb = t % v.L;
@@ -319,7 +351,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             const int wx0 = wxi * WIN, wy0 = wyi * WIN;
             const int gxa = gwx[wxi], gxb = gwx[wxi + 1], gya = gwy[wyi], gyb = gwy[wyi + 1];   // [gxa,gxb) x [gya,gyb)
             const int nx_ = gxb - gxa, ny_ = gyb - gya;
-            __syncthreads();                               // previous window fully done with LDS
+            BAR_LDS();                                     // previous window fully done with LDS
             // ---- phase 0: clear the counters, local index maps ----------------------------------------------------
             {
                 uint4* c4 = reinterpret_cast<uint4*>(s.cnt);
@@ -332,7 +364,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     s_bb[0] = INT_MAX; s_bb[1] = -1; s_bb[2] = INT_MAX; s_bb[3] = -1;
                 }
             }
-            __syncthreads();
+            BAR_LDS();
             STAMP(1);
 
             // ---- phase 1: flag the cells that receive an "occupied" or "nearby" hit; clip every ray to the window ----
@@ -385,7 +417,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     for (int k = 0; k < nch; ++k) if (base + k < CH_CAP) s.chunk[base + k] = (uint16_t)((b << 3) | k);
                 }
             }
-            __syncthreads();
+            BAR_LDS();
             // rank of every flagged cell among the window's flagged cells = its bucket id (cell order)
             {
                 const int w = tid;                          // one flag word per thread (WIN*WIN/32 == MU_BLOCK)
@@ -393,7 +425,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 int pc = __popc(bits), incl = pc;
                 for (int off = 1; off < 64; off <<= 1) { int n = __shfl_up(incl, off, 64); if (lane >= off) incl += n; }
                 if (lane == 63) s_wsum[wave] = incl;
-                __syncthreads();
+                BAR_LDS();
                 int wbase = 0;
                 for (int k = 0; k < wave; ++k) wbase += s_wsum[k];
                 const int excl = wbase + incl - pc;
@@ -402,14 +434,14 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 uint32_t bb = bits; int id = excl;
                 while (bb) { int bit = __ffs(bb) - 1; bb &= bb - 1; if (id < NB) s.bcell[id] = (uint16_t)(w * 32 + bit); ++id; }
             }
-            __syncthreads();
+            BAR_LDS();
             // event slots are shared out evenly: few flagged cells (a near wall under dense beams) get deep buckets
             const int nflag = s_nflag;
             const int cap = min(64, max(4, EV_TOT / max(nflag, 1)));
             const int nbk = min(min(nflag, NB), EV_TOT / cap);
             STAMP(2);
 
-            // ---- phase 2: walk the clipped rays, CHUNK steps per work item ------------------------------------------
+            // ---- phase 2: walk the clipped rays, CHUNK steps per work item, four steps in flight ------------------------
             {
                 const int nchunk = min(s_nchunk, CH_CAP);
                 if (s_nchunk > CH_CAP && tid == 0) atomicCAS(v.err, 0, RBPF_ENOMEM);   // cannot happen: B*5 entries
@@ -428,108 +460,66 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     const bool near_ok = info & RI_NEAR;
                     int m = ray_minor_at(r, jlo);
                     int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;   // hybridmap.py:289-300 invariant
-                    for (int j = jlo; j <= jhi; ++j) {
-                        const int maj = m0 + smaj * j, mnr = n0 + smin * m;
-                        const int ix = (r.steep ? mnr : maj) - gxa, iy = (r.steep ? maj : mnr) - gya;
-                        if (D >= 0) { ++m; D -= 2 * r.dmaj; }
-                        D += 2 * r.dmin;
-                        if ((unsigned)ix >= (unsigned)nx_ || (unsigned)iy >= (unsigned)ny_) continue;
-                        const int c = s.lutx[ix] * WIN + s.luty[iy];
-                        const int sh = (c & 1) * 16;
-                        const uint32_t old = atomicAdd(&s.cnt[c >> 1], 1u << sh);
-                        const uint32_t h = (old >> sh) & 0xFFFFu;
-                        if (h & 0x8000u) {                  // flagged: the counter value is the slot in the cell's bucket
-                            const int id = s.fpre[c >> 5] + __popc(s.flag[c >> 5] & ((1u << (c & 31)) - 1u));
+                    for (int j4 = jlo; j4 <= jhi; j4 += 4) {
+                        int c[4]; uint32_t h[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {                     // four cells: index math + counter reads
+                            const int j = j4 + u;
+                            const int maj = m0 + smaj * j, mnr = n0 + smin * m;
+                            const int ix = (r.steep ? mnr : maj) - gxa, iy = (r.steep ? maj : mnr) - gya;
+                            if (D >= 0) { ++m; D -= 2 * r.dmaj; }
+                            D += 2 * r.dmin;
+                            const bool in = j <= jhi && (unsigned)ix < (unsigned)nx_ && (unsigned)iy < (unsigned)ny_;
+                            c[u] = in ? s.lutx[in ? ix : 0] * WIN + s.luty[in ? iy : 0] : -1;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) h[u] = c[u] >= 0 ? (s.cnt[c[u] >> 1] >> ((c[u] & 1) * 16)) & 0xFFFFu : 0u;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            // an unflagged cell only needs min(n, sat) hits: max(v + n*emp, vmin) is vmin for every
+                            // n >= sat.  The plain read above is a broadcast; skipping spares the serialised
+                            // same-address atomics of the cells next to the sensor, which every ray crosses.
+                            if (c[u] < 0 || (h[u] - (uint32_t)sat < 0x8000u - (uint32_t)sat)) { h[u] = 0; continue; }
+                            const int sh = (c[u] & 1) * 16;
+                            h[u] = (atomicAdd(&s.cnt[c[u] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (!(h[u] & 0x8000u)) continue;  // flagged: the counter value is the slot in the cell's bucket
+                            const int cc = c[u], j = j4 + u;
+                            const int id = s.fpre[cc >> 5] + __popc(s.flag[cc >> 5] & ((1u << (cc & 31)) - 1u));
                             const int rem = r.n - 1 - j;
                             const int rank = (rem == 0) ? (occ ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
-                            int pos = (int)(h & 0x7FFFu);
+                            int pos = (int)(h[u] & 0x7FFFu);
                             if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | rank);
                             if (near_ok && rem == 1) {
-                                const uint32_t old2 = atomicAdd(&s.cnt[c >> 1], 1u << sh);
-                                pos = (int)((old2 >> sh) & 0x7FFFu);
+                                const int sh = (cc & 1) * 16;
+                                pos = (int)((atomicAdd(&s.cnt[cc >> 1], 1u << sh) >> sh) & 0x7FFFu);
                                 if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | EV_NEAR);
                             }
                         }
                     }
                 }
             }
-            __syncthreads();
+            BAR_LDS();
             STAMP(3);
 
-            // ---- phase 3a: cells that only received "empty" hits: v = max(v + n*emp, min) ---------------------------
-            int my_written = 0;
-            int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
-            {
-                constexpr int PER = 4;                                  // 32-bit words (4 cells) in flight per thread
-                for (int i0 = 0; i0 < WIN * WIN / 4 / MU_BLOCK; i0 += PER) {
-                uint32_t wd[PER], n01[PER], n23[PER];
-                uint32_t* gp[PER];
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {                         // all loads first: the read-modify-write is latency-bound
-                    const int q = tid + (i0 + i) * MU_BLOCK;
-                    const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
-                    uint32_t w0 = s.cnt[(lx * WIN + ly) >> 1], w1 = s.cnt[((lx * WIN + ly) >> 1) + 1];
-                    if (w0 & 0x00008000u) w0 &= 0xFFFF0000u;            // flagged cells are replayed in phase 3b
-                    if (w0 & 0x80000000u) w0 &= 0x0000FFFFu;
-                    if (w1 & 0x00008000u) w1 &= 0xFFFF0000u;
-                    if (w1 & 0x80000000u) w1 &= 0x0000FFFFu;
-                    n01[i] = w0; n23[i] = w1;
-                    gp[i] = reinterpret_cast<uint32_t*>(tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly));
-                    wd[i] = (w0 | w1) ? *gp[i] : 0u;
-                }
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    if (!(n01[i] | n23[i])) continue;
-                    const int q = tid + (i0 + i) * MU_BLOCK;
-                    const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
-                    const uint32_t n[4] = {n01[i] & 0xFFFFu, n01[i] >> 16, n23[i] & 0xFFFFu, n23[i] >> 16};
-                    uint32_t word = wd[i];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (n[k]) {
-                            int val = (int)(int8_t)((word >> (8 * k)) & 0xFFu);
-                            val = cell_emp_n(val, (int)n[k], v.cc);
-                            word = (word & ~(0xFFu << (8 * k))) | (((uint32_t)val & 0xFFu) << (8 * k));
-                            ++my_written;
-                            by0 = min(by0, wy0 + ly + k); by1 = max(by1, wy0 + ly + k);
-                        }
-                    }
-                    *gp[i] = word;
-                    bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
-                }
-                }
-            }
-            __syncthreads();   // flagged cells share 32-bit words with phase-3a cells: finish 3a first
-            STAMP(4);
-
-            // ---- phase 3b: flagged cells, ordered replay from their buckets ------------------------------------------
+            // ---- phase 3: flagged cells, ordered replay; the new value goes back into the cell's LDS slot ----------------
             // (the chunk table is dead now: its memory holds the two work lists of this phase)
-            uint16_t* bigc = s.chunk;                       // buckets of 9..cap events: folded by one wave each
+            uint16_t* bigc = s.chunk;                       // buckets of 17..cap events: folded by one wave each
             uint16_t* slowc = s.chunk + NB;                 // bucket overflow / no bucket: exact membership scan
             for (int id = tid; id < min(nflag, NB); id += MU_BLOCK) {
                 const int c = s.bcell[id];
                 const int m = id < nbk ? (int)(cnt16_get(s.cnt, c) & 0x7FFFu) : INT_MAX;
                 if (m > cap) { slowc[atomicAdd(&s_nslow, 1)] = (uint16_t)c; continue; }
-                if (m > SMALL_BUCKET) { bigc[atomicAdd(&s_nbig, 1)] = (uint16_t)id; continue; }
+                if (m > 16) { bigc[atomicAdd(&s_nbig, 1)] = (uint16_t)id; continue; }
                 const int lx = c / WIN, ly = c % WIN;
-                int8_t* gpc = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
-                int val = *gpc;
-                uint32_t ev[SMALL_BUCKET];
-#pragma unroll
-                for (int e = 0; e < SMALL_BUCKET; ++e) ev[e] = e < m ? (uint32_t)s.bev[id * cap + e] : 0xFFFFFFFFu;
-                // replay in ascending (beam, rank): selection by repeated minimum over registers
-                for (int k = 0; k < m; ++k) {
-                    uint32_t best = 0xFFFFFFFFu; int be = 0;
-#pragma unroll
-                    for (int e = 0; e < SMALL_BUCKET; ++e) if (ev[e] < best) { best = ev[e]; be = e; }
-#pragma unroll
-                    for (int e = 0; e < SMALL_BUCKET; ++e) if (e == be) ev[e] = 0xFFFFFFFFu;
-                    val = cell_apply_rank(val, (int)(best & 7u), v.cc);
-                }
-                *gpc = (int8_t)val;
-                ++my_written;
-                bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
-                by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
+                int val = tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)];
+                // replay in ascending (beam, rank): bitonic sorting network over registers, then a sequential fold
+                const uint16_t* evp = s.bev + id * cap;
+                if (m <= 8) val = replay_sorted<8>(evp, m, val, v.cc);
+                else val = replay_sorted<16>(evp, m, val, v.cc);
+                cnt16_set(s.cnt, c, 0x8000u | ((uint32_t)val & 0xFFu));
             }
             if (nflag > NB) {   // more flagged cells than bucket ids: the rest is replayed by membership scan
                 for (int id = NB + tid; id < nflag; id += MU_BLOCK) {
@@ -543,14 +533,13 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     if (pos < CH_CAP - NB) slowc[pos] = (uint16_t)c; else atomicCAS(v.err, 0, RBPF_ENOMEM);
                 }
             }
-            __syncthreads();
-            // ---- phase 3c: deep buckets and bucket-less cells, one wave per cell -----------------------------------------
+            BAR_LDS();
             {
                 const int nbig = s_nbig;
                 for (int k = wave; k < nbig; k += MU_BLOCK / 64) {
                     const int id = bigc[k];
                     const int c = s.bcell[id];
-                    const int m = (int)(cnt16_get(s.cnt, c) & 0x7FFFu);            // 9..64 events, one per lane
+                    const int m = (int)(cnt16_get(s.cnt, c) & 0x7FFFu);            // 17..64 events, one per lane
                     const uint32_t key = lane < m ? (uint32_t)s.bev[id * cap + lane] : 0xFFFFFFFFu;
                     int rank = 0;
                     for (int e = 0; e < m; ++e) {
@@ -573,39 +562,73 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     }
                     if (lane == 0) {
                         const int lx = c / WIN, ly = c % WIN;
-                        int8_t* gpc = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
-                        *gpc = (int8_t)caf_apply(f, (int)*gpc);
-                        ++my_written;
-                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
-                        by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
+                        int val = caf_apply(f, (int)tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)]);
+                        cnt16_set(s.cnt, c, 0x8000u | ((uint32_t)val & 0xFFu));
                     }
                 }
                 const int nslow = min(s_nslow, CH_CAP - NB);
                 for (int k = wave; k < nslow; k += MU_BLOCK / 64) {
                     const int c = slowc[k];
                     const int lx = c / WIN, ly = c % WIN;
-                    int8_t* gpc = tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly);
                     int gxc[4], gyc[4], ngx = 0, ngy = 0;
                     for (int i = 0; i < nx_ && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
                     for (int i = 0; i < ny_ && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
-                    int val = replay_cell_wave(v, s, x0, y0, gxc, ngx, gyc, ngy, (int)*gpc, lane);
-                    if (lane == 0) {
-                        *gpc = (int8_t)val;
-                        ++my_written;
-                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
-                        by0 = min(by0, wy0 + ly); by1 = max(by1, wy0 + ly);
-                    }
+                    int val = replay_cell_wave(v, s, x0, y0, gxc, ngx, gyc, ngy,
+                                               (int)tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)], lane);
+                    if (lane == 0) cnt16_set(s.cnt, c, 0x8000u | ((uint32_t)val & 0xFFu));
                 }
                 if (tid == 0 && nslow) s_tot_slow += nslow;
             }
+            BAR_LDS();
+            STAMP(4);
+
+            // ---- phase 4: one read-modify-write of every touched 4-cell word -------------------------------------------
+            //      unflagged cell: v = max(v + n*emp, min) (gridmap.py:97-101, n times); flagged cell: the replayed value
+            int my_written = 0;
+            int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
+            {
+                constexpr int PER = 4;                                  // words in flight per thread
+                for (int i0 = 0; i0 < WIN * WIN / 4 / MU_BLOCK; i0 += PER) {
+                    uint32_t wd[PER], n01[PER], n23[PER];
+                    uint32_t* gp[PER];
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {                     // all loads first: the read-modify-write is latency-bound
+                        const int q = tid + (i0 + i) * MU_BLOCK;
+                        const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
+                        n01[i] = s.cnt[(lx * WIN + ly) >> 1]; n23[i] = s.cnt[((lx * WIN + ly) >> 1) + 1];
+                        gp[i] = reinterpret_cast<uint32_t*>(tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly));
+                        wd[i] = (n01[i] | n23[i]) ? *gp[i] : 0u;
+                    }
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        if (!(n01[i] | n23[i])) continue;
+                        const int q = tid + (i0 + i) * MU_BLOCK;
+                        const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
+                        const uint32_t n[4] = {n01[i] & 0xFFFFu, n01[i] >> 16, n23[i] & 0xFFFFu, n23[i] >> 16};
+                        uint32_t word = wd[i];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (n[k]) {
+                                int val;
+                                if (n[k] & 0x8000u) val = (int)(int8_t)(n[k] & 0xFFu);
+                                else val = cell_emp_n((int)(int8_t)((word >> (8 * k)) & 0xFFu), (int)n[k], v.cc);
+                                word = (word & ~(0xFFu << (8 * k))) | (((uint32_t)val & 0xFFu) << (8 * k));
+                                ++my_written;
+                                by0 = min(by0, wy0 + ly + k); by1 = max(by1, wy0 + ly + k);
+                            }
+                        }
+                        *gp[i] = word;
+                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+                    }
+                }
+            }
             STAMP(5);
-            // ---- phase 4: bounding box of written cells (bounds resample copies), counters ---------------------------
             if (my_written) {
                 atomicAdd(&s_written, my_written);
                 atomicMin(&s_bb[0], bx0); atomicMax(&s_bb[1], bx1);
                 atomicMin(&s_bb[2], by0); atomicMax(&s_bb[3], by1);
             }
-            __syncthreads();
+            BAR_LDS();
             STAMP(6);
             if (tid == 0 && s_written) {
                 s_tot_written += s_written;
