@@ -32,10 +32,12 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = ["-DRBPF_STAMPS"] if os.environ.get("RBPF_STAMPS") else []   # diagnostic build: per-phase cycle stamps
+    extra = []   # diagnostic builds: per-phase cycle stamps in ONE kernel (RBPF_STAMPS=mapupdate | match)
+    stamp_target = os.environ.get("RBPF_STAMPS", "")
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        extra = ["-DRBPF_STAMPS"] if stamp_target and stamp_target in src else []
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -582,44 +582,63 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             BAR_LDS();
             STAMP(4);
 
-            // ---- phase 4: one read-modify-write of every touched 4-cell word -------------------------------------------
-            //      unflagged cell: v = max(v + n*emp, min) (gridmap.py:97-101, n times); flagged cell: the replayed value
+            // ---- phase 4: one read-modify-write per touched 32-cell group (one group per thread) ----------------------
+            //      unflagged cell: v = max(v + n*emp, min) (gridmap.py:97-101, n times); flagged cell: the replayed value.
+            //      The group's word of the tile's occupancy bitmask (cell > threshold, gridmap.py:153; read by the scan
+            //      matcher) is rebuilt from the 32 new values.
             int my_written = 0;
             int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
             {
-                constexpr int PER = 4;                                  // words in flight per thread
-                for (int i0 = 0; i0 < WIN * WIN / 4 / MU_BLOCK; i0 += PER) {
-                    uint32_t wd[PER], n01[PER], n23[PER];
-                    uint32_t* gp[PER];
+                const int lx = tid / (WIN / 32), g = tid % (WIN / 32);       // 128 rows x 4 groups = 512 threads
+                const int ly = g * 32;
+                const uint4* c4 = reinterpret_cast<const uint4*>(s.cnt + ((lx * WIN + ly) >> 1));
+                uint32_t n[16];
+                {
+                    const uint4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+                    n[0] = q0.x; n[1] = q0.y; n[2] = q0.z; n[3] = q0.w; n[4] = q1.x; n[5] = q1.y; n[6] = q1.z; n[7] = q1.w;
+                    n[8] = q2.x; n[9] = q2.y; n[10] = q2.z; n[11] = q2.w; n[12] = q3.x; n[13] = q3.y; n[14] = q3.z; n[15] = q3.w;
+                }
+                uint32_t any = 0;
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) {                     // all loads first: the read-modify-write is latency-bound
-                        const int q = tid + (i0 + i) * MU_BLOCK;
-                        const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
-                        n01[i] = s.cnt[(lx * WIN + ly) >> 1]; n23[i] = s.cnt[((lx * WIN + ly) >> 1) + 1];
-                        gp[i] = reinterpret_cast<uint32_t*>(tile_base + (size_t)(wx0 + lx) * v.dim + (wy0 + ly));
-                        wd[i] = (n01[i] | n23[i]) ? *gp[i] : 0u;
+                for (int k = 0; k < 16; ++k) any |= n[k];
+                const int row = wx0 + lx, col = wy0 + ly;
+                if (any && row < v.dim && col < v.dim) {
+                    uint32_t* gp = reinterpret_cast<uint32_t*>(tile_base + (size_t)row * v.dim + col);
+                    const int nw = min(8, (v.dim - col) >> 2);               // words inside the row (dim is a multiple of 16)
+                    uint32_t wd[8];
+                    if (nw == 8) {
+                        const uint4 a0 = reinterpret_cast<const uint4*>(gp)[0], a1 = reinterpret_cast<const uint4*>(gp)[1];
+                        wd[0] = a0.x; wd[1] = a0.y; wd[2] = a0.z; wd[3] = a0.w; wd[4] = a1.x; wd[5] = a1.y; wd[6] = a1.z; wd[7] = a1.w;
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) wd[w] = w < nw ? gp[w] : 0u;
                     }
+                    uint32_t occ = 0;
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) {
-                        if (!(n01[i] | n23[i])) continue;
-                        const int q = tid + (i0 + i) * MU_BLOCK;
-                        const int lx = q / (WIN / 4), ly = (q % (WIN / 4)) * 4;
-                        const uint32_t n[4] = {n01[i] & 0xFFFFu, n01[i] >> 16, n23[i] & 0xFFFFu, n23[i] >> 16};
-                        uint32_t word = wd[i];
+                    for (int w = 0; w < 8; ++w) {
+                        uint32_t word = wd[w];
+                        const uint32_t cw0 = n[2 * w], cw1 = n[2 * w + 1];
+                        if (cw0 | cw1) {
+                            const uint32_t nn[4] = {cw0 & 0xFFFFu, cw0 >> 16, cw1 & 0xFFFFu, cw1 >> 16};
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (n[k]) {
-                                int val;
-                                if (n[k] & 0x8000u) val = (int)(int8_t)(n[k] & 0xFFu);
-                                else val = cell_emp_n((int)(int8_t)((word >> (8 * k)) & 0xFFu), (int)n[k], v.cc);
-                                word = (word & ~(0xFFu << (8 * k))) | (((uint32_t)val & 0xFFu) << (8 * k));
-                                ++my_written;
-                                by0 = min(by0, wy0 + ly + k); by1 = max(by1, wy0 + ly + k);
+                            for (int k = 0; k < 4; ++k) {
+                                if (nn[k]) {
+                                    int val;
+                                    if (nn[k] & 0x8000u) val = (int)(int8_t)(nn[k] & 0xFFu);
+                                    else val = cell_emp_n((int)(int8_t)((word >> (8 * k)) & 0xFFu), (int)nn[k], v.cc);
+                                    word = (word & ~(0xFFu << (8 * k))) | (((uint32_t)val & 0xFFu) << (8 * k));
+                                    ++my_written;
+                                    by0 = min(by0, col + 4 * w + k); by1 = max(by1, col + 4 * w + k);
+                                }
                             }
+                            if (w < nw) gp[w] = word;
                         }
-                        *gp[i] = word;
-                        bx0 = min(bx0, wx0 + lx); bx1 = max(bx1, wx0 + lx);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            occ |= ((int)(int8_t)((word >> (8 * k)) & 0xFFu) > v.cc.thr ? 1u : 0u) << (4 * w + k);
                     }
+                    v.occ[((size_t)tile * v.dim + row) * v.ow + (col >> 5)] = occ;
+                    bx0 = row; bx1 = row;
                 }
             }
             STAMP(5);

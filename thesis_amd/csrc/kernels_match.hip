@@ -27,6 +27,13 @@
 
 namespace rbpf {
 
+#ifdef RBPF_STAMPS
+#define MSTAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define MSTAMP(k) do { } while (0)
+#endif
+
+static const int MBLOCK = 512;          // threads per particle (8 waves)
 static const int M_COARSE = 4;          // coarse cell = 4 fine cells
 static const int M_FINE_T = 4;          // fine translations: -4..4 cells around the coarse optimum
 static const int M_FINE_R = 4;          // fine rotations:   -4..4 steps of d0
@@ -54,6 +61,8 @@ struct MatchLds {
     uint32_t* dil;      // [N][N/32]
     uint32_t* crs;      // [N/4][words]
     float* bx; float* by;   // [nb] selected beams in matcher-cell units
+    float* fx4; float* fy4; // [ceil(nb/4) padded to 4] every 4th beam (fine level), contiguous
+    float* cx8; float* cy8; // [ceil(nb/8) padded to 4] every 8th beam (coarse level), contiguous
     int* sc;            // [n coarse candidates] then reused for fine
 };
 
@@ -63,7 +72,8 @@ size_t match_lds_bytes(int N, int B, int n_coarse) {
     size_t words = (size_t)N * (N / 32);
     int fine = (2 * M_FINE_R + 1) * (2 * M_FINE_T + 1) * (2 * M_FINE_T + 1);
     size_t nsc = (size_t)(n_coarse > fine ? n_coarse : fine);
-    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + (size_t)B * 8 + nsc * 4 + 128;
+    size_t dec = (size_t)(((B + 3) / 4 + 7) & ~3) + (size_t)(((B + 7) / 8 + 7) & ~3);
+    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + (size_t)((B + 3) & ~3) * 8 + dec * 8 + nsc * 4 + 256;
 }
 
 __device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w) {
@@ -78,7 +88,7 @@ __device__ __forceinline__ int coarse_hit(const MatchLds& s, int N, int u, int w
     return (s.crs[cu * match_crs_words(N) + (cw >> 5)] >> (cw & 31)) & 1u;
 }
 
-__global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
+__global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, W = N >> 5, tid = threadIdx.x, p = blockIdx.x;
     MatchLds s;
@@ -86,13 +96,19 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
     s.dil = s.occ + (size_t)N * W;
     s.crs = s.dil + (size_t)N * W;
     s.bx = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N));
-    s.by = s.bx + a.cap_sel;
-    s.sc = reinterpret_cast<int*>(s.by + a.cap_sel);
+    const int capb = (a.cap_sel + 3) & ~3, cap4 = ((a.cap_sel + 3) / 4 + 7) & ~3, cap8 = ((a.cap_sel + 7) / 8 + 7) & ~3;
+    s.by = s.bx + capb;
+    s.fx4 = s.by + capb; s.fy4 = s.fx4 + cap4;
+    s.cx8 = s.fy4 + cap4; s.cy8 = s.cx8 + cap8;
+    s.sc = reinterpret_cast<int*>(s.cy8 + cap8);
     __shared__ double s_g[3], s_rng[2];
     __shared__ int s_org[2], s_nb, s_best, s_bestc;
     __shared__ double s_mom[10];
     __shared__ int s_tab[49];
 
+#ifdef RBPF_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#endif
     // ---- guess, search window (robot.py:62-65), region origin ----------------------------------------------
     if (tid == 0) {
         double gx, gy, gth, rx, ry;
@@ -113,39 +129,91 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
     }
     if (!a.single) {
         const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * v.L * v.L;
-        for (int i = tid; i < v.L * v.L; i += BLOCK) s_tab[i] = tab[i];
+        for (int i = tid; i < v.L * v.L; i += MBLOCK) s_tab[i] = tab[i];
     }
-    for (int i = tid; i < N * W; i += BLOCK) { s.occ[i] = 0; s.dil[i] = 0; }
-    for (int i = tid; i < (N / M_COARSE) * match_crs_words(N); i += BLOCK) s.crs[i] = 0;
+    for (int i = tid; i < N * W; i += MBLOCK) { s.occ[i] = 0; s.dil[i] = 0; }
+    for (int i = tid; i < (N / M_COARSE) * match_crs_words(N); i += MBLOCK) s.crs[i] = 0;
     __syncthreads();
     const int ox = s_org[0], oy = s_org[1];
 
+    MSTAMP(0);
     // ---- field ------------------------------------------------------------------------------------------------
     if (a.mode == 0) {
-        // occupancy of the particle's own map over the region (cells > threshold, gridmap.py:153)
-        const size_t cells = (size_t)v.dim * v.dim;
-        for (int q = tid; q < N * W; q += BLOCK) {
-            const int u = q / W, wv = q % W;
-            uint32_t bits = 0;
-            for (int du = 0; du < a.ds; ++du) {
-                const int gxi = (ox + u) * a.ds + du;
-                if (!lut_valid_g(v, gxi)) continue;
-                const uint32_t ex = lut_at(v, gxi);
-                for (int b = 0; b < 32 * a.ds; ++b) {
-                    const int gyi = (oy + wv * 32) * a.ds + b;
-                    if (!lut_valid_g(v, gyi)) continue;
-                    const uint32_t ey = lut_at(v, gyi);
-                    const int t = s_tab[lut_lat(ex) * v.L + lut_lat(ey)];
-                    if (t < 0) continue;
-                    int val = v.pool[(size_t)t * cells + (size_t)lut_cidx(ex) * v.dim + lut_cidx(ey)];
-                    if (val > v.cc.thr) bits |= 1u << (b / a.ds);
-                }
-            }
-            s.occ[q] = bits;
+        // occupancy of the particle's own map over the region: bits of the per-tile occupancy masks kept by the
+        // map-update kernel (cell > threshold, gridmap.py:153), re-addressed through the global-index LUT
+        int16_t* colmap = reinterpret_cast<int16_t*>(s.sc);     // [N*ds] (lat << 12 | cidx) of every region column
+        uint32_t* rowbase = s.dil;                              // [N*ds] word offset of every region row in the mask pool
+        for (int i = tid; i < N * a.ds; i += MBLOCK) {
+            const int gyi = oy * a.ds + i, gxi = ox * a.ds + i;
+            int16_t e = -1;
+            if (lut_valid_g(v, gyi)) { const uint32_t ey = lut_at(v, gyi); e = (int16_t)((lut_lat(ey) << 12) | lut_cidx(ey)); }
+            colmap[i] = e;
+            uint32_t rb = 0xFFFFFFFFu;                          // high byte = lattice row of the tile table, low 24 bits = storage row
+            if (lut_valid_g(v, gxi)) { const uint32_t ex = lut_at(v, gxi); rb = ((uint32_t)lut_lat(ex) << 24) | (uint32_t)lut_cidx(ex); }
+            rowbase[i] = rb;
         }
+        __syncthreads();
+        for (int q0 = tid; q0 < N * W; q0 += 4 * MBLOCK) {
+            uint32_t lo[4], hi[4], hi2[4]; int sh[4]; bool fast[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                       // issue the mask loads of four words first
+                const int q = q0 + k * MBLOCK;
+                lo[k] = hi[k] = hi2[k] = 0; sh[k] = 0; fast[k] = false;
+                if (q >= N * W || a.ds != 1) continue;
+                const int u = q / W, wv = q % W;
+                const uint32_t rb = rowbase[u];
+                const int e0 = colmap[wv * 32], e1 = colmap[wv * 32 + 31];
+                // 32 region columns of one tile whose storage columns lie in [e0-1, e0+33]: the isolated off-by-one
+                // glitches of the reference's index formula keep every column inside a 96-bit window
+                if (rb == 0xFFFFFFFFu || e0 < 0 || e1 < 0 || (e0 >> 12) != (e1 >> 12) || e1 - e0 > 33 || e1 - e0 < 29) continue;
+                fast[k] = true;
+                const int t = s_tab[(rb >> 24) * v.L + (e0 >> 12)];
+                if (t < 0) continue;
+                const int cy = max((e0 & 0xFFF) - 1, 0);
+                const uint32_t* row = v.occ + ((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow;
+                lo[k] = row[cy >> 5];
+                hi[k] = ((cy >> 5) + 1 < v.ow) ? row[(cy >> 5) + 1] : 0u;
+                hi2[k] = ((cy >> 5) + 2 < v.ow) ? row[(cy >> 5) + 2] : 0u;
+                sh[k] = (cy >> 5) << 5;                         // first storage column of the loaded window
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + k * MBLOCK;
+                if (q >= N * W) continue;
+                uint32_t bits;
+                if (fast[k]) {
+                    bits = 0;
+                    const int wv = q % W;
+#pragma unroll 8
+                    for (int b = 0; b < 32; ++b) {
+                        const int pcol = (colmap[wv * 32 + b] & 0xFFF) - sh[k];             // 0..95
+                        const uint32_t wsel = pcol < 32 ? lo[k] : pcol < 64 ? hi[k] : hi2[k];
+                        bits |= ((wsel >> (pcol & 31)) & 1u) << b;
+                    }
+                } else {                                          // LUT glitch, tile edge or coarser matcher cell: bit by bit
+                    bits = 0;
+                    const int u = q / W, wv = q % W;
+                    for (int du = 0; du < a.ds; ++du) {
+                        const uint32_t rb = rowbase[u * a.ds + du];
+                        if (rb == 0xFFFFFFFFu) continue;
+                        for (int b = 0; b < 32 * a.ds; ++b) {
+                            const int e = colmap[wv * 32 * a.ds + b];
+                            if (e < 0) continue;
+                            const int t = s_tab[(rb >> 24) * v.L + (e >> 12)];
+                            if (t < 0) continue;
+                            const int cy = e & 0xFFF;
+                            const uint32_t wd = v.occ[((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow + (cy >> 5)];
+                            if ((wd >> (cy & 31)) & 1u) bits |= 1u << (b / a.ds);
+                        }
+                    }
+                }
+                s.occ[q] = bits;
+            }
+        }
+        __syncthreads();                                        // colmap memory is the score table again below
     } else {
         // occupancy rasterised from reference points (previous accepted scan, hybridmap.py:167-171)
-        for (int i = tid; i < a.n_ref; i += BLOCK) {
+        for (int i = tid; i < a.n_ref; i += MBLOCK) {
             double rx = a.ref_xy[2 * i], ry = a.ref_xy[2 * i + 1];
             double dx = rx - s_g[0], dy = ry - s_g[1];
             if (!(sqrt(dx * dx + dy * dy) < a.max_range)) continue;   // hybridmap.py:171 (11 m); matchScanCustom.m:11 (15 m)
@@ -154,11 +222,18 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
         }
     }
     // selected beams (in matcher-cell units, sensor frame)
-    for (int b = tid; b < a.n_sel; b += BLOCK) { s.bx[b] = (float)((double)a.sel_x[b] / a.mcs); s.by[b] = (float)((double)a.sel_y[b] / a.mcs); }
-    if (tid == 0) s_nb = a.n_sel;
+    {
+        const float inv = (float)(1.0 / a.mcs);
+        const float FAR = -1.0e6f;                          // padding beams fall outside the region: no hit
+        for (int b = tid; b < a.n_sel; b += MBLOCK) { s.bx[b] = a.sel_x[b] * inv; s.by[b] = a.sel_y[b] * inv; }
+        for (int i = tid; i < cap4; i += MBLOCK) { const int b = 4 * i; const bool ok = b < a.n_sel; s.fx4[i] = ok ? a.sel_x[b] * inv : FAR; s.fy4[i] = ok ? a.sel_y[b] * inv : FAR; }
+        for (int i = tid; i < cap8; i += MBLOCK) { const int b = 8 * i; const bool ok = b < a.n_sel; s.cx8[i] = ok ? a.sel_x[b] * inv : FAR; s.cy8[i] = ok ? a.sel_y[b] * inv : FAR; }
+        if (tid == 0) s_nb = a.n_sel;
+    }
     __syncthreads();
+    MSTAMP(1);
     // 3x3 dilation and 4x4 max-pool of the dilated field
-    for (int q = tid; q < N * W; q += BLOCK) {
+    for (int q = tid; q < N * W; q += MBLOCK) {
         const int u = q / W, wv = q % W;
         uint32_t acc = 0;
         for (int du = -1; du <= 1; ++du) {
@@ -171,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
         s.dil[q] = acc;
     }
     __syncthreads();
-    for (int q = tid; q < N * W; q += BLOCK) {
+    for (int q = tid; q < N * W; q += MBLOCK) {
         uint32_t d = s.dil[q];
         if (!d) continue;
         const int u = q / W, wv = q % W;
@@ -194,26 +269,60 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
     const int nr = 2 * a.n_coarse_rot + 1;
     const int n_coarse = nr * ntx * nty;
 
+    MSTAMP(2);
+    // Neighbouring translation candidates along y are consecutive bits of one mask row, so one LDS read scores a whole
+    // row of them: a work item is (rotation, x translation); its per-candidate sums are byte lanes of two registers.
+    const int n8 = ((nb + 7) / 8 + 3) & ~3, n4 = ((nb + 3) / 4 + 3) & ~3;       // padded with far-away beams
+    const float gthf = (float)remainder(gth, 6.283185307179586);
+    const int CW = match_crs_words(N);
+    const int NC4 = N / M_COARSE;
     // ---- coarse level -------------------------------------------------------------------------------------------
-    for (int cnd = tid; cnd < n_coarse; cnd += BLOCK) {
-        const int ir = cnd / (ntx * nty), it = cnd % (ntx * nty);
-        double snd, csd;
-        sincos(gth + (double)(ir - a.n_coarse_rot) * M_COARSE * a.d0, &snd, &csd);
-        const float sn = (float)snd, cs = (float)csd;
-        const float tx = fx + (float)((it / nty - max(ktx, 0)) * M_COARSE), ty = fy + (float)((it % nty - max(kty, 0)) * M_COARSE);
-        int sc = 0;
-        for (int b = 0; b < nb; b += 8) {
-            float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
-            sc += coarse_hit(s, N, (int)floorf(ex), (int)floorf(ey));
+    for (int item = tid; item < nr * ntx; item += MBLOCK) {
+        const int ir = item / ntx, itx = item % ntx;
+        float sn, cs;
+        __sincosf(gthf + (float)((double)(ir - a.n_coarse_rot) * M_COARSE * a.d0), &sn, &cs);
+        const float tx = fx + (float)((itx - max(ktx, 0)) * M_COARSE);
+        for (int g0 = 0; g0 < nty; g0 += 8) {                       // up to 8 y translations per pass
+            const float ty0 = fy + (float)((g0 - max(kty, 0)) * M_COARSE);
+            int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int bb = 0; bb < n8; bb += 240) {                  // byte-lane sums stay below 256
+                uint32_t accA = 0, accB = 0;
+                const int be = min(n8, bb + 240);
+                for (int b = bb; b < be; b += 4) {
+                    const float4 bx4 = *reinterpret_cast<const float4*>(s.cx8 + b), by4 = *reinterpret_cast<const float4*>(s.cy8 + b);
+                    const float ex[4] = {cs * bx4.x - sn * by4.x + tx, cs * bx4.y - sn * by4.y + tx, cs * bx4.z - sn * by4.z + tx, cs * bx4.w - sn * by4.w + tx};
+                    const float ey[4] = {sn * bx4.x + cs * by4.x + ty0, sn * bx4.y + cs * by4.y + ty0, sn * bx4.z + cs * by4.z + ty0, sn * bx4.w + cs * by4.w + ty0};
+                    uint32_t lo[4], hi[4]; int sh[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int u = (int)floorf(ex[k]), w0 = (int)floorf(ey[k]);
+                        const int cu = u >> 2, cw0 = w0 >> 2;       // candidate j of this pass looks at coarse column cw0 + j
+                        const bool in = (unsigned)u < (unsigned)N && cw0 >= 0 && cw0 + 7 < NC4;
+                        const int i0 = in ? cu * CW + (cw0 >> 5) : 0;
+                        sh[k] = cw0 & 31;
+                        lo[k] = in ? s.crs[i0] : 0u;
+                        hi[k] = (in && sh[k] > 24 && (cw0 >> 5) + 1 < CW) ? s.crs[i0 + 1] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t bits = ((lo[k] >> sh[k]) | (sh[k] ? hi[k] << (32 - sh[k]) : 0u)) & 0xFFu;
+                        accA += ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+                        accB += ((bits >> 4) * 0x00204081u) & 0x01010101u;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sum[j] += (accA >> (8 * j)) & 0xFFu; sum[4 + j] += (accB >> (8 * j)) & 0xFFu; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (g0 + j < nty) { s.sc[(ir * ntx + itx) * nty + g0 + j] = sum[j]; atomicMax(&s_best, sum[j]); }
         }
-        s.sc[cnd] = sc;
-        atomicMax(&s_best, sc);
     }
     __syncthreads();
     if (tid == 0) s_bestc = INT_MAX;
     __syncthreads();
     const int best_coarse = s_best;
-    for (int cnd = tid; cnd < n_coarse; cnd += BLOCK) {
+    for (int cnd = tid; cnd < n_coarse; cnd += MBLOCK) {
         if (s.sc[cnd] == best_coarse) {
             // ties: the candidate closest to the guess, then the lowest index (deterministic)
             const int ir = cnd / (ntx * nty), it = cnd % (ntx * nty);
@@ -227,36 +336,76 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
     const int cir = cbest / (ntx * nty) - a.n_coarse_rot, cit = cbest % (ntx * nty);
     const int ctx = (cit / nty - max(ktx, 0)) * M_COARSE, cty = (cit % nty - max(kty, 0)) * M_COARSE;
     __syncthreads();
+    const int FR = 2 * M_FINE_R + 1, FT = 2 * M_FINE_T + 1;
+    const int n_fine = FR * FT * FT;
+    for (int i = tid; i < n_fine; i += MBLOCK) s.sc[i] = 0;
     if (tid == 0) s_best = INT_MIN;
     __syncthreads();
 
+    MSTAMP(3);
     // ---- fine level -----------------------------------------------------------------------------------------------
-    const int FR = 2 * M_FINE_R + 1, FT = 2 * M_FINE_T + 1;
-    const int n_fine = FR * FT * FT;
-    for (int cnd = tid; cnd < n_fine; cnd += BLOCK) {
+    // work item = (rotation, x translation, beam slice); the 9 y translations are 9 consecutive bits of the rows
+    {
+        const int NS = 6;                                           // 9 * 9 * 6 = 486 items for 512 threads
+        const int per = (((n4 + NS - 1) / NS) + 3) & ~3;
+        for (int item = tid; item < FR * FT * NS; item += MBLOCK) {
+            const int sl = item % NS, ix = (item / NS) % FT - M_FINE_T, ir = item / (NS * FT) - M_FINE_R;
+            const double dth = (double)(cir * M_COARSE + ir) * a.d0;
+            float sn, cs;
+            __sincosf(gthf + (float)dth, &sn, &cs);
+            const float tx = fx + (float)(ctx + ix), ty0 = fy + (float)(cty - M_FINE_T);
+            int sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const int b_lo = sl * per, b_hi = min(n4, b_lo + per);
+            for (int bb = b_lo; bb < b_hi; bb += 120) {             // two fields per beam: byte lanes stay below 256
+                uint32_t accA = 0, accB = 0; int accC = 0;
+                const int be = min(b_hi, bb + 120);
+                for (int b = bb; b < be; b += 4) {
+                    const float4 bx4 = *reinterpret_cast<const float4*>(s.fx4 + b), by4 = *reinterpret_cast<const float4*>(s.fy4 + b);
+                    const float ex[4] = {cs * bx4.x - sn * by4.x + tx, cs * bx4.y - sn * by4.y + tx, cs * bx4.z - sn * by4.z + tx, cs * bx4.w - sn * by4.w + tx};
+                    const float ey[4] = {sn * bx4.x + cs * by4.x + ty0, sn * bx4.y + cs * by4.y + ty0, sn * bx4.z + cs * by4.z + ty0, sn * bx4.w + cs * by4.w + ty0};
+                    uint32_t ol[4], oh[4], dl[4], dh[4]; int sh[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int u = (int)floorf(ex[k]), w0 = (int)floorf(ey[k]);
+                        const bool in = (unsigned)u < (unsigned)N && w0 >= 0 && w0 + 8 < N;
+                        const int i0 = in ? u * W + (w0 >> 5) : 0;
+                        sh[k] = w0 & 31;
+                        const bool two = in && sh[k] > 23 && (w0 >> 5) + 1 < W;
+                        ol[k] = in ? s.occ[i0] : 0u; dl[k] = in ? s.dil[i0] : 0u;
+                        oh[k] = two ? s.occ[i0 + 1] : 0u; dh[k] = two ? s.dil[i0 + 1] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t bo = ((ol[k] >> sh[k]) | (sh[k] ? oh[k] << (32 - sh[k]) : 0u)) & 0x1FFu;
+                        const uint32_t bd = ((dl[k] >> sh[k]) | (sh[k] ? dh[k] << (32 - sh[k]) : 0u)) & 0x1FFu;
+                        accA += (((bo & 0xFu) * 0x00204081u) & 0x01010101u) + (((bd & 0xFu) * 0x00204081u) & 0x01010101u);
+                        accB += ((((bo >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) + ((((bd >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+                        accC += (int)(bo >> 8) + (int)(bd >> 8);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sum[j] += (accA >> (8 * j)) & 0xFFu; sum[4 + j] += (accB >> (8 * j)) & 0xFFu; }
+                sum[8] += accC;
+            }
+            const int base = ((ir + M_FINE_R) * FT + (ix + M_FINE_T)) * FT;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) if (sum[j]) atomicAdd(&s.sc[base + j], sum[j]);
+        }
+    }
+    __syncthreads();
+    for (int cnd = tid; cnd < n_fine; cnd += MBLOCK) {
         const int ir = cnd / (FT * FT) - M_FINE_R, ix = (cnd / FT) % FT - M_FINE_T, iy = cnd % FT - M_FINE_T;
         const double dth = (double)(cir * M_COARSE + ir) * a.d0;
         const int dx = ctx + ix, dy = cty + iy;
-        int sc = -1;                                   // -1: outside the search window
-        if (fabs(dth) < a.rot_range && fabs((double)dx) < rxc && fabs((double)dy) < ryc) {
-            double snd, csd;
-            sincos(gth + dth, &snd, &csd);
-            const float sn = (float)snd, cs = (float)csd;
-            const float tx = fx + (float)dx, ty = fy + (float)dy;
-            sc = 0;
-            for (int b = 0; b < nb; b += 4) {
-                float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
-                sc += field_hit(s, N, (int)floorf(ex), (int)floorf(ey));
-            }
-        }
-        s.sc[cnd] = sc;
-        atomicMax(&s_best, sc);
+        // candidates outside the search window (matchScanCustom.m:52-57) do not take part
+        if (!(fabs(dth) < a.rot_range && fabs((double)dx) < rxc && fabs((double)dy) < ryc)) s.sc[cnd] = -1;
+        atomicMax(&s_best, s.sc[cnd]);
     }
     __syncthreads();
     if (tid == 0) s_bestc = INT_MAX;
     __syncthreads();
     const int best = s_best;
-    for (int cnd = tid; cnd < n_fine; cnd += BLOCK) {
+    for (int cnd = tid; cnd < n_fine; cnd += MBLOCK) {
         if (s.sc[cnd] == best) {
             const int ir = cnd / (FT * FT) - M_FINE_R, ix = (cnd / FT) % FT - M_FINE_T, iy = cnd % FT - M_FINE_T;
             int dr = cir * M_COARSE + ir, dx = ctx + ix, dy = cty + iy;
@@ -269,6 +418,7 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
     const double bth = (double)(cir * M_COARSE + (fbest / (FT * FT) - M_FINE_R)) * a.d0;
     const double bdx = (double)(ctx + (fbest / FT) % FT - M_FINE_T) * a.mcs, bdy = (double)(cty + fbest % FT - M_FINE_T) * a.mcs;
 
+    MSTAMP(4);
     // score of the selected pose over ALL beams (the search levels subsample them)
     __syncthreads();
     if (tid == 0) s_best = 0;
@@ -279,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
         const float sn = (float)snd, cs = (float)csd;
         const float tx = fx + (float)(bdx / a.mcs), ty = fy + (float)(bdy / a.mcs);
         int sc = 0;
-        for (int b = tid; b < nb; b += BLOCK) {
+        for (int b = tid; b < nb; b += MBLOCK) {
             float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
             sc += field_hit(s, N, (int)floorf(ex), (int)floorf(ey));
         }
@@ -293,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
     {
         const double tau = fmax(1.0, 0.02 * (double)((nb + 3) / 4) * 2.0);
         double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int cnd = tid; cnd < n_fine; cnd += BLOCK) {
+        for (int cnd = tid; cnd < n_fine; cnd += MBLOCK) {
             int sc = s.sc[cnd];
             if (sc < 0) continue;
             const int ir = cnd / (FT * FT) - M_FINE_R, ix = (cnd / FT) % FT - M_FINE_T, iy = cnd % FT - M_FINE_T;
@@ -310,6 +460,10 @@ __global__ __launch_bounds__(BLOCK) void match_kernel(DevView v, MatchArgs a) {
         }
     }
     __syncthreads();
+    MSTAMP(5);
+#ifdef RBPF_STAMPS
+    if (tid == 0) for (int k = 0; k < 6; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+#endif
     if (tid == 0) {
         double* o = a.out + (size_t)p * 13;
         const bool ok = best > 0 && nb > 0;                       // no overlap at all: matchScanCustom.m:25-28
@@ -362,7 +516,7 @@ static void launch_match(const DevView& v, const MatchArgs& a, int grid, size_t 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(BLOCK), lds, s, v, a);
+    hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, v, a);
 }
 
 void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,

@@ -242,6 +242,12 @@ __device__ __forceinline__ void copy_rows(int8_t* dst, const int8_t* src, int di
     }
 }
 
+// occupancy-bitmask rows x0..x1 of a tile (whole rows: ow words each); src == nullptr zero-fills
+__device__ __forceinline__ void copy_occ_rows(uint32_t* dst, const uint32_t* src, int ow, int x0, int x1, int tid) {
+    const int n = (x1 - x0 + 1) * ow;
+    for (int q = tid; q < n; q += BLOCK) dst[(size_t)x0 * ow + q] = src ? src[(size_t)x0 * ow + q] : 0u;
+}
+
 __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
     __shared__ int s_item, s_tile;
     const DevView& v = a.v;
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
             int x0 = min(sb[0], db[0]), x1 = max(sb[1], db[1]), y0 = min(sb[2], db[2]), y1 = max(sb[3], db[3]);
             if (x0 <= x1 && y0 <= y1) {
                 copy_rows(v.pool + (size_t)td * cells, v.pool + (size_t)ts * cells, v.dim, x0, x1, y0, y1, tid);
+                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, v.occ + (size_t)ts * v.dim * v.ow, v.ow, x0, x1, tid);
                 if (tid == 0) {
                     const int ya = y0 & ~15, yb = min((y1 | 15) + 1, v.dim);
                     atomicAdd(&v.stats[ST_COPY_BYTES], 2ull * (unsigned long long)(x1 - x0 + 1) * (yb - ya));
@@ -291,7 +298,10 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
             int db[4];
             for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
             if (db[0] <= db[1] && db[2] <= db[3])
+            {
                 copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], tid);
+            }
             if (tid == 0) {
                 v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1;
                 v.tile_bbox[4 * td + 2] = INT_MAX; v.tile_bbox[4 * td + 3] = -1;

@@ -183,7 +183,10 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         }
         ALLOC(h, v.px, P); ALLOC(h, v.py, P); ALLOC(h, v.pth, P); ALLOC(h, v.cov, 9 * P); ALLOC(h, v.weight, P);
         ALLOC(h, v.slot, P); ALLOC(h, v.global_id, P);
+        v.ow = (dim + 31) / 32;
         ALLOC(h, v.tile_tab, P * LL); ALLOC(h, v.pool, (size_t)v.pool_tiles * cells);
+        ALLOC(h, v.occ, (size_t)v.pool_tiles * dim * v.ow);
+        HIP_TRY(h, hipMemset(v.occ, 0, (size_t)v.pool_tiles * dim * v.ow * 4));
         ALLOC(h, v.tile_bbox, (size_t)v.pool_tiles * 4); ALLOC(h, v.free_stack, v.pool_tiles); ALLOC(h, v.free_top, 1);
         double* dtmp; uint8_t* btmp;
         ALLOC(h, dtmp, (size_t)c.max_beams); v.bx = dtmp;
@@ -679,6 +682,13 @@ int rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const 
         HIP_TRY(h, hipMemcpy(v.tile_tab + (size_t)slot * LL + idx, &t, 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(h, hipMemcpy(v.pool + (size_t)t * v.dim * v.dim, cells, (size_t)v.dim * v.dim, hipMemcpyHostToDevice));
+    {   // occupancy bitmask of the uploaded cells (cell > threshold, gridmap.py:153)
+        std::vector<uint32_t> occ((size_t)v.dim * v.ow, 0u);
+        for (int x = 0; x < v.dim; ++x)
+            for (int y = 0; y < v.dim; ++y)
+                if ((int)cells[(size_t)x * v.dim + y] > v.cc.thr) occ[(size_t)x * v.ow + (y >> 5)] |= 1u << (y & 31);
+        HIP_TRY(h, hipMemcpy(v.occ + (size_t)t * v.dim * v.ow, occ.data(), occ.size() * 4, hipMemcpyHostToDevice));
+    }
     int32_t bb[4] = {0, v.dim - 1, 0, v.dim - 1};       // unknown content: the whole tile counts as written
     HIP_TRY(h, hipMemcpy(v.tile_bbox + 4 * (size_t)t, bb, sizeof(bb), hipMemcpyHostToDevice));
     return RBPF_OK;

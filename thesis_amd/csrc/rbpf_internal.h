@@ -40,6 +40,8 @@ struct DevView {
     // maps
     int32_t* tile_tab;                 // [P slots][L*L] pool tile id or -1
     int8_t*  pool;                     // [pool_tiles][dim*dim], cell[x*dim + y]
+    uint32_t* occ;                     // [pool_tiles][dim][ow] occupancy bits (cell > threshold), bit y&31 of word y>>5
+    int ow;                            // words per occupancy row = ceil(dim / 32)
     int32_t* tile_bbox;                // [pool_tiles][4] x_min, x_max, y_min, y_max (inclusive)
     int32_t* free_stack;               // [pool_tiles]
     int32_t* free_top;                 // [1] number of free tiles on the stack
