@@ -47,11 +47,12 @@ def parse():
 class Runner:
     """The reference's event loop body for accepted scans, on one rank."""
 
-    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None):
+    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None, device=0):
         from thesis_amd.engine import ParticleEngine
         self.P, self.B, self.rank, self.world = P, B, rank, world
         self.angles, self.ranges, self.odo, self.true_poses = log
-        self.e = ParticleEngine(P, max_beams=B, cell_size=cell_size, pool_tiles=2 * P + 64, seed=42 + rank)
+        # the seed is global: proposal streams are keyed by (seed, step, global particle id)
+        self.e = ParticleEngine(P, max_beams=B, cell_size=cell_size, pool_tiles=2 * P + 64, seed=42, device=device)
         self.shard = shard
         if shard is not None:
             shard.attach(self.e)
@@ -136,7 +137,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("RBPF_FORCE_DIST"))     # rehearse the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -145,14 +147,10 @@ def main():
     log = synthetic.make_log(n_scans, args.beams, period=PERIOD_S)
 
     shard = None
-    if world > 1:
+    if dist is not None:
         from thesis_amd.sharding import ShardedResampler
-        shard = ShardedResampler(rank, world, args.particles, device=local_rank)
-    os.environ.setdefault("RBPF_DEVICE", str(local_rank))
-    run = Runner(args.particles, args.beams, args.cell_size, log, rank, world, shard)
-    if world > 1:
-        run.e.close()
-        raise SystemExit("sharded path is wired in a later step")
+        shard = ShardedResampler(rank, world, args.particles, device=local_rank, dist=dist)
+    run = Runner(args.particles, args.beams, args.cell_size, log, rank, world, shard, device=local_rank)
 
     def barrier():
         if dist is not None:
@@ -172,7 +170,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        moved = torch.tensor([float(shard.stats["moved"]), float(shard.stats["bytes_sent"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(moved)
     if rank != 0:
+        run.e.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     P_total = args.particles * world
@@ -211,6 +215,10 @@ def main():
                       "particles_per_gpu": args.particles, "beams": args.beams, "cell_size": args.cell_size,
                       "parallelism": f"particles sharded x{world}"},
            "roofline": roofline}
+    if dist is not None:
+        out["collective"] = {"weights": "one RCCL all-reduce of %d float64 per step" % P_total,
+                             "migrated_particles_per_step": float(moved[0].item()) / (2 * max(1, args.steps + args.warmup)),
+                             "migrated_bytes_per_step": float(moved[1].item()) / max(1, args.steps + args.warmup)}
     run.e.close()
     if not args.no_target_run and world == 1:
         # north-star target size: >= 10k particles x 1081 beams on one GPU (not `value`)
@@ -235,6 +243,9 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(log, args.beams, args.cell_size)
     print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -150,20 +150,29 @@ int  rbpf_match_inputs(rbpf_handle* h, int32_t particle, const double* guess3, d
  * idx_out[P] (may be NULL) receives the ancestor index of every new particle. */
 int  rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resample);
 
-/* multi-GPU pieces (one handle per rank; the collective itself is the caller's, over RCCL):
- * scatter the local weights into a zeroed device vector of n_global doubles at the global ids
- * of this handle's particles, so that an all-reduce(sum) yields the full weight vector ...      */
+/* multi-GPU pieces (one handle per rank; the collectives themselves are the caller's, over RCCL).
+ * Every particle carries a global id (0 .. n_global-1, its index in the reference's particle list); the
+ * Philox proposal streams are keyed by it, so results do not depend on which rank holds a particle. */
+int  rbpf_set_global_ids(rbpf_handle* h, const int32_t* ids_p);
+/* zero a device vector of n_global doubles and scatter the local weights into it at the global ids, so that
+ * an all-reduce(sum) yields the full weight vector on every rank ...                                       */
 int  rbpf_export_weights(rbpf_handle* h, void* d_global_weights, int32_t n_global);
-/* ... then compute the global systematic-resampling indices from it on every rank (identical),
- * idx_out[n_global] on the host. */
+/* ... then compute the global systematic-resampling ancestors from it (main.py:46-67), identically on every
+ * rank; idx_out[n_global] on the host. */
 int  rbpf_resample_indices_global(rbpf_handle* h, const void* d_global_weights, int32_t n_global,
                                   double u, int32_t* idx_out, int32_t* did_resample);
-/* apply a migration plan locally: new_src[P] = local source slot of each new local particle or
- * -1 when it arrives from another rank (then filled by rbpf_unpack_particles).                 */
+/* serialise n local particles (state + the written boxes of their tiles + occupancy masks) into d_buf;
+ * meta_out[n * rbpf_pack_meta_width()] describes the layout for the receiver (host ints) */
+int32_t rbpf_pack_meta_width(rbpf_handle* h);
+int64_t rbpf_packed_particle_bytes(rbpf_handle* h);     /* upper bound of one particle's payload */
+int  rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_buf, int64_t cap_bytes,
+                         int32_t* meta_out, int64_t* bytes_out);
+/* local part of a global resample: new local particle j continues local particle new_src[j] (sorted ascending)
+ * or, for new_src[j] = -1 (last), arrives from another rank and is installed by rbpf_unpack_particles; weights
+ * restart at 1.0 (main.py:77-78) */
 int  rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int32_t* new_global_id);
-int64_t rbpf_packed_particle_bytes(rbpf_handle* h);
-int  rbpf_pack_particles(rbpf_handle* h, const int32_t* slots, int32_t n, void* d_buf);
-int  rbpf_unpack_particles(rbpf_handle* h, const int32_t* slots, int32_t n, const void* d_buf);
+int  rbpf_unpack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, const void* d_buf,
+                           const int32_t* meta_in);
 
 /* ---- state access (Robot.get_latest_pose/weight, HybridMap readback; main.py:152,170-176) ----- */
 int  rbpf_get_poses(rbpf_handle* h, double* out_p3);

@@ -1,0 +1,173 @@
+"""The N > 1 path on CPU: migration plan properties and a world_size-2 gloo run of ShardedResampler against a
+numpy particle store (test double), checked against the oracle's single-process resample (main.py:46-79)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import rbpf_oracle as orc
+from thesis_amd.sharding import plan_migration
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("world,p_local,seed", [(2, 8, 0), (4, 16, 1), (8, 32, 2), (8, 4, 3)])
+def test_plan_migration_properties(world, p_local, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = world * p_local
+    # a previous, arbitrary placement
+    perm = rng.permutation(n)
+    owner = np.empty(n, dtype=np.int32); local_of = np.empty(n, dtype=np.int32)
+    owner[perm] = np.arange(n) // p_local
+    local_of[perm] = np.arange(n) % p_local
+    w = np.exp(rng.normal(0, 3, n)) * 1000
+    did, idx = orc.resample_indices(list(w), float(rng.random()))
+    assert did
+    idx = np.array(idx)
+    plan = plan_migration(idx, owner, local_of, world, p_local)
+    assert np.array_equal(np.bincount(plan.dest, minlength=world), np.full(world, p_local))
+    n_src = np.bincount(owner[idx], minlength=world)
+    assert plan.n_move == int(np.maximum(n_src - p_local, 0).sum())          # only the surplus migrates
+    seen = np.zeros(n, dtype=bool)
+    for r in range(world):
+        gid, src = plan.new_gid[r], plan.new_src[r]
+        assert len(gid) == p_local and not seen[gid].any()
+        seen[gid] = True
+        kept = src >= 0
+        assert np.all(np.diff(src[kept]) >= 0) and not kept[np.argmax(~kept):].any() if (~kept).any() else True
+        assert np.array_equal(local_of[idx[gid[kept]]], src[kept]) and np.all(owner[idx[gid[kept]]] == r)
+        arrivals = gid[~kept]
+        expected = np.concatenate([gid_q for gid_q in ([np.sort(np.nonzero((plan.src_rank == q) & (plan.dest == r))[0])
+                                                         for q in range(world) if q != r])]) if (~kept).any() else arrivals
+        assert np.array_equal(arrivals, expected)                            # arrival order = all-to-all order
+        for q in range(world):
+            if q != r:
+                js = np.sort(np.nonzero((plan.src_rank == q) & (plan.dest == r))[0])
+                assert np.array_equal(plan.send[q][r], local_of[idx[js]])
+    assert seen.all()
+
+
+class NumpyShard:
+    """Test double of EngineShard: particles are (13 doubles, 48-byte map tag) records in numpy."""
+    meta_width = 4
+
+    def __init__(self, states, tags):
+        import torch
+        self.torch = torch
+        self.states, self.tags = [s.copy() for s in states], [t.copy() for t in tags]
+        self.gids = None
+
+    def set_global_ids(self, ids):
+        self.gids = np.array(ids)
+
+    def weights_global(self, n):
+        t = self.torch.zeros(n, dtype=self.torch.float64)
+        t[self.torch.from_numpy(self.gids.astype(np.int64))] = self.torch.tensor([s[12] for s in self.states], dtype=self.torch.float64)
+        return t
+
+    def indices(self, w, u):
+        did, idx = orc.resample_indices(list(w.numpy()), u)
+        return did, np.array(idx, dtype=np.int32)
+
+    def pack(self, local_idx):
+        n = len(local_idx)
+        meta = np.zeros((n, 4), dtype=np.int32)
+        chunks = []
+        for i, li in enumerate(local_idx):
+            rec = np.zeros(176, dtype=np.uint8)
+            rec[:104] = np.frombuffer(self.states[li].tobytes(), dtype=np.uint8)
+            rec[128:176] = self.tags[li]
+            meta[i] = [1, 176 // 16, 0, 0]
+            chunks.append(rec)
+        pay = self.torch.from_numpy(np.concatenate(chunks)) if chunks else self.torch.empty(0, dtype=self.torch.uint8)
+        return meta, pay
+
+    def empty_payload(self, n):
+        return self.torch.empty(n, dtype=self.torch.uint8)
+
+    def apply_local(self, new_src, new_gid):
+        ns, nt = [], []
+        for s in new_src:
+            if s >= 0:
+                st = self.states[s].copy(); st[12] = 1.0
+                ns.append(st); nt.append(self.tags[s].copy())
+            else:
+                ns.append(None); nt.append(None)
+        self.states, self.tags, self.gids = ns, nt, np.array(new_gid)
+
+    def unpack(self, local_idx, meta, payload):
+        buf = payload.numpy()
+        off = 0
+        for i, li in enumerate(local_idx):
+            st = np.frombuffer(buf[off:off + 104].tobytes(), dtype=np.float64).copy(); st[12] = 1.0
+            self.states[li] = st; self.tags[li] = buf[off + 128:off + 176].copy()
+            off += int(meta[i][1]) * 16
+
+    def pose(self, i):
+        return self.states[i][:3]
+
+
+def _worker(rank, world, p_local, port, rounds, out_q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from thesis_amd.sharding import ShardedResampler
+    n = world * p_local
+    rng = np.random.Generator(np.random.PCG64(42))
+    states = rng.normal(size=(n, 13)); tags = rng.integers(0, 255, size=(n, 48)).astype(np.uint8)
+    sl = slice(rank * p_local, (rank + 1) * p_local)
+    shard = NumpyShard(list(states[sl]), list(tags[sl]))
+    sr = ShardedResampler(rank, world, p_local)
+    sr.attach(shard)
+    history = []
+    for k in range(rounds):
+        wts = np.exp(rng.normal(0, 3, n)) * 1000           # same on every rank: new weights per global id
+        for i, g in enumerate(shard.gids):
+            shard.states[i][12] = wts[g]
+        did, idx = sr.resample(0.37 + 0.1 * k)
+        history.append((did, None if idx is None else idx.copy()))
+        p0 = sr.pose_of_particle0()
+    out_q.put((rank, shard.gids.copy(), np.array(shard.states), np.array(shard.tags), history, p0, sr.stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,p_local", [(2, 8), (2, 33)])
+def test_sharded_resample_gloo_matches_single_process(world, p_local):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    rounds = 3
+    procs = [ctx.Process(target=_worker, args=(r, world, p_local, port, rounds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process expectation
+    n = world * p_local
+    rng = np.random.Generator(np.random.PCG64(42))
+    states = rng.normal(size=(n, 13)); tags = rng.integers(0, 255, size=(n, 48)).astype(np.uint8)
+    for k in range(rounds):
+        wts = np.exp(rng.normal(0, 3, n)) * 1000
+        did, idx = orc.resample_indices(list(wts), 0.37 + 0.1 * k)
+        assert did
+        idx = np.array(idx)
+        states, tags = states[idx].copy(), tags[idx].copy()
+        states[:, 12] = 1.0
+        for res in results:
+            assert res[4][k][0] and np.array_equal(res[4][k][1], idx)          # same ancestors on every rank
+    got_s, got_t = np.empty_like(states), np.empty_like(tags)
+    seen = np.zeros(n, dtype=bool)
+    for rank, gids, st, tg, hist, p0, stats in results:
+        got_s[gids] = st; got_t[gids] = tg; seen[gids] = True
+        np.testing.assert_array_equal(p0, states[0, :3])
+    assert seen.all()
+    np.testing.assert_array_equal(got_s, states)
+    np.testing.assert_array_equal(got_t, tags)

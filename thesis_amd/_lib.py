@@ -67,9 +67,11 @@ PROTOTYPES = {
     "rbpf_export_weights": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "rbpf_resample_indices_global": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_double, _I, _I]),
     "rbpf_apply_resample_local": (C.c_int, [_H, _I, _I]),
+    "rbpf_set_global_ids": (C.c_int, [_H, _I]),
+    "rbpf_pack_meta_width": (C.c_int32, [_H]),
     "rbpf_packed_particle_bytes": (C.c_int64, [_H]),
-    "rbpf_pack_particles": (C.c_int, [_H, _I, C.c_int32, C.c_void_p]),
-    "rbpf_unpack_particles": (C.c_int, [_H, _I, C.c_int32, C.c_void_p]),
+    "rbpf_pack_particles": (C.c_int, [_H, _I, C.c_int32, C.c_void_p, C.c_int64, _I, C.POINTER(C.c_int64)]),
+    "rbpf_unpack_particles": (C.c_int, [_H, _I, C.c_int32, C.c_void_p, _I]),
     "rbpf_get_poses": (C.c_int, [_H, _D]),
     "rbpf_get_covs": (C.c_int, [_H, _D]),
     "rbpf_get_weights": (C.c_int, [_H, _D]),

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     s.sc = reinterpret_cast<int*>(s.cy8 + cap8);
     __shared__ double s_g[3], s_rng[2];
     __shared__ int s_org[2], s_nb, s_best, s_bestc;
-    __shared__ double s_mom[10];
+    __shared__ double s_mom[10], s_wmom[MBLOCK / 64][10];
     __shared__ int s_tab[49];
 
 #ifdef RBPF_STAMPS
@@ -453,12 +453,14 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
             m[0] += w; m[1] += w * ex; m[2] += w * ey; m[3] += w * et;
             m[4] += w * ex * ex; m[5] += w * ex * ey; m[6] += w * ex * et; m[7] += w * ey * ey; m[8] += w * ey * et; m[9] += w * et * et;
         }
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 10; ++k) {                    // fixed-order reduction: results must not depend on wave timing
             double x = m[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-            if ((tid & 63) == 0) atomicAdd(&s_mom[k], x);
+            if ((tid & 63) == 0) s_wmom[tid >> 6][k] = x;
         }
     }
+    __syncthreads();
+    if (tid < 10) { double x = 0.0; for (int w = 0; w < MBLOCK / 64; ++w) x += s_wmom[w][tid]; s_mom[tid] = x; }
     __syncthreads();
     MSTAMP(5);
 #ifdef RBPF_STAMPS

@@ -151,6 +151,7 @@ struct PairArgs {
     int32_t* dead_list;       // [P] scratch
     int32_t* jobs;            // [P][2] src slot, dst slot
     int32_t* n_jobs;          // [1] (+ queue head behind it)
+    int32_t* err;
 };
 
 __device__ int block_exclusive_scan_1024(int val, int* s_buf, int tid, int& total) {
@@ -185,23 +186,30 @@ __global__ __launch_bounds__(PLAN_THREADS) void resample_pair_kernel(PairArgs a)
     for (int i = i0; i < i1; ++i)
         if ((a.T[i] - (i > 0 ? a.T[i - 1] : 0)) == 0) a.dead_list[base++] = i;
     __syncthreads();
-    // duplicates: new particle j whose ancestor equals that of j-1 (main.py:70-74)
-    int n_dup = 0;
-    for (int j = i0; j < i1; ++j) n_dup += (j > 0 && a.idx[j] == a.idx[j - 1]);
-    int total_dup;
-    int dbase = block_exclusive_scan_1024(n_dup, s_buf, tid, total_dup);
+    // duplicates: new particle j whose ancestor equals that of j-1 (main.py:70-74); idx < 0 marks a particle that
+    // arrives from another rank: it takes a dead particle's map slot too, but nothing is copied for it here
+    int n_dup = 0, n_job = 0;
     for (int j = i0; j < i1; ++j) {
-        int src = a.slot_old[a.idx[j]];
-        if (j > 0 && a.idx[j] == a.idx[j - 1]) {
+        const bool in = a.idx[j] < 0, dup = !in && j > 0 && a.idx[j] == a.idx[j - 1];
+        n_dup += in || dup; n_job += dup;
+    }
+    int total_dup, total_job;
+    int dbase = block_exclusive_scan_1024(n_dup, s_buf, tid, total_dup);
+    __syncthreads();
+    int jbase = block_exclusive_scan_1024(n_job, s_buf, tid, total_job);
+    for (int j = i0; j < i1; ++j) {
+        const bool in = a.idx[j] < 0, dup = !in && j > 0 && a.idx[j] == a.idx[j - 1];
+        if (in || dup) {
             int dst = a.slot_old[a.dead_list[dbase]];
-            a.jobs[2 * dbase] = src; a.jobs[2 * dbase + 1] = dst;
+            if (dup) { a.jobs[2 * jbase] = a.slot_old[a.idx[j]]; a.jobs[2 * jbase + 1] = dst; ++jbase; }
             a.slot_new[j] = dst;
             ++dbase;
         } else {
-            a.slot_new[j] = src;
+            a.slot_new[j] = a.slot_old[a.idx[j]];
         }
     }
-    if (tid == 0) { a.n_jobs[0] = total_dup; a.n_jobs[1] = 0; }
+    if (tid == 0 && total_dup != total_dead) atomicCAS(a.err, 0, RBPF_ESTATE);
+    if (tid == 0) { a.n_jobs[0] = total_job; a.n_jobs[1] = 0; }
 }
 
 // ---- kernel 4: permute the small per-particle state, weights <- 1.0 (main.py:77-78) ---------------------
@@ -215,6 +223,7 @@ __global__ void resample_gather_kernel(GatherArgs a) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.P) return;
     const int i = a.idx[j];
+    if (i < 0) return;                 // arrives from another rank: filled by the unpack kernel
     a.px2[j] = a.px[i]; a.py2[j] = a.py[i]; a.pth2[j] = a.pth[i];
 #pragma unroll
     for (int k = 0; k < 9; ++k) a.cov2[(size_t)k * a.P + j] = a.cov[(size_t)k * a.P + i];
@@ -323,6 +332,160 @@ __global__ void resample_release_kernel(DevView v, const int32_t* pending, int32
     if (threadIdx.x == 0) *n_pending = 0;
 }
 
+// ---- multi-GPU pieces -------------------------------------------------------------------------------------------
+// scatter the local weights to their global particle ids (the caller all-reduces the vector over RCCL)
+__global__ void export_weights_kernel(int P, const double* __restrict__ w, const int32_t* __restrict__ gid,
+                                      double* __restrict__ out, int n_global) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P && gid[p] >= 0 && gid[p] < n_global) out[gid[p]] = w[p];
+}
+
+// T[i] = number of new local particles whose source is an old local particle <= i (sources sorted ascending, -1 last)
+__global__ __launch_bounds__(PLAN_THREADS) void sources_to_T_kernel(int P, const int32_t* __restrict__ idx, int32_t* __restrict__ T,
+                                                                     int32_t* __restrict__ did) {
+    __shared__ int s_buf[PLAN_THREADS];
+    const int tid = threadIdx.x, nt = PLAN_THREADS;
+    const int chunk = (P + nt - 1) / nt;
+    const int i0 = min(tid * chunk, P), i1 = min(i0 + chunk, P);
+    for (int i = i0; i < i1; ++i) T[i] = 0;
+    __syncthreads();
+    for (int j = i0; j < i1; ++j) if (idx[j] >= 0) atomicAdd(&T[idx[j]], 1);
+    __syncthreads();
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += T[i];
+    int total;
+    int run = block_exclusive_scan_1024(sum, s_buf, tid, total);
+    for (int i = i0; i < i1; ++i) { run += T[i]; T[i] = run; }
+    if (tid == 0) *did = 1;
+}
+
+// tile ids and written boxes of n particles -> out[n][LL*5] (tile id, x0, x1, y0, y1)
+__global__ void gather_meta_kernel(DevView v, const int32_t* __restrict__ local_idx, int n, int32_t* __restrict__ out) {
+    const int LL = v.L * v.L;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n * LL) return;
+    const int i = q / LL, pos = q % LL;
+    const int t = v.tile_tab[(size_t)v.slot[local_idx[i]] * LL + pos];
+    int32_t* o = out + (size_t)q * 5;
+    o[0] = t;
+    for (int k = 0; k < 4; ++k) o[1 + k] = t >= 0 ? v.tile_bbox[4 * t + k] : 0;
+}
+
+struct PackJob { int32_t particle, tile, x0, x1, ya, yb; long long off; };   // particle = local index; tile < 0: state block
+
+__global__ __launch_bounds__(BLOCK) void pack_kernel(DevView v, const PackJob* __restrict__ jobs, unsigned char* __restrict__ buf) {
+    const PackJob j = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    unsigned char* dst = buf + j.off;
+    if (j.tile < 0) {                                   // 13 doubles: pose, covariance, weight
+        if (tid < 13) {
+            const int p = j.particle;
+            double val = tid == 0 ? v.px[p] : tid == 1 ? v.py[p] : tid == 2 ? v.pth[p]
+                       : tid < 12 ? v.cov[(size_t)(tid - 3) * v.P + p] : v.weight[p];
+            reinterpret_cast<double*>(dst)[tid] = val;
+        }
+        return;
+    }
+    const size_t cells = (size_t)v.dim * v.dim;
+    const int8_t* src = v.pool + (size_t)j.tile * cells;
+    const int per_row = (j.yb - j.ya) / 16, rows = j.x1 - j.x0 + 1;
+    for (int q = tid; q < rows * per_row; q += BLOCK) {
+        const int x = j.x0 + q / per_row, y = j.ya + (q % per_row) * 16;
+        reinterpret_cast<uint4*>(dst)[q] = *reinterpret_cast<const uint4*>(src + (size_t)x * v.dim + y);
+    }
+    uint32_t* docc = reinterpret_cast<uint32_t*>(dst + (size_t)rows * per_row * 16);
+    const uint32_t* socc = v.occ + ((size_t)j.tile * v.dim + j.x0) * v.ow;
+    for (int q = tid; q < rows * v.ow; q += BLOCK) docc[q] = socc[q];
+}
+
+// one workgroup per (incoming particle, lattice position): install the received tile (or release the slot's old one)
+struct UnpackJob { int32_t particle, pos, has, x0, x1, ya, yb, pad; long long off; };
+
+__global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJob* __restrict__ jobs, const unsigned char* __restrict__ buf,
+                                                       int32_t* pending_free, int32_t* n_pending) {
+    __shared__ int s_tile;
+    const UnpackJob j = jobs[blockIdx.x];
+    const int tid = threadIdx.x, LL = v.L * v.L;
+    if (j.pos < 0) {                                    // state block
+        if (tid < 13) {
+            const double val = reinterpret_cast<const double*>(buf + j.off)[tid];
+            const int p = j.particle;
+            if (tid == 0) v.px[p] = val; else if (tid == 1) v.py[p] = val; else if (tid == 2) v.pth[p] = val;
+            else if (tid < 12) v.cov[(size_t)(tid - 3) * v.P + p] = val; else v.weight[p] = 1.0;   // main.py:77-78
+        }
+        return;
+    }
+    const int slot = v.slot[j.particle];
+    int td = v.tile_tab[(size_t)slot * LL + j.pos];
+    const size_t cells = (size_t)v.dim * v.dim;
+    if (!j.has) {
+        if (td < 0) return;
+        int db[4];
+        for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
+        if (db[0] <= db[1] && db[2] <= db[3]) {
+            copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], tid);
+        }
+        if (tid == 0) {
+            v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1; v.tile_bbox[4 * td + 2] = INT_MAX; v.tile_bbox[4 * td + 3] = -1;
+            v.tile_tab[(size_t)slot * LL + j.pos] = -1;
+            pending_free[atomicAdd(n_pending, 1)] = td;
+        }
+        return;
+    }
+    if (td < 0) {
+        if (tid == 0) {
+            int idx = atomicSub(v.free_top, 1) - 1;
+            if (idx < 0) { atomicAdd(v.free_top, 1); atomicCAS(v.err, 0, RBPF_ENOMEM); s_tile = -1; }
+            else { s_tile = v.free_stack[idx]; v.tile_tab[(size_t)slot * LL + j.pos] = s_tile; }
+        }
+        __syncthreads();
+        td = s_tile;
+        if (td < 0) return;
+    } else {                                            // wipe what the slot's previous owner had written
+        int db[4];
+        for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
+        if (db[0] <= db[1] && db[2] <= db[3]) {
+            copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], tid);
+        }
+        __syncthreads();
+    }
+    if (j.x0 <= j.x1) {
+        const unsigned char* src = buf + j.off;
+        int8_t* dst = v.pool + (size_t)td * cells;
+        const int per_row = (j.yb - j.ya) / 16, rows = j.x1 - j.x0 + 1;
+        for (int q = tid; q < rows * per_row; q += BLOCK) {
+            const int x = j.x0 + q / per_row, y = j.ya + (q % per_row) * 16;
+            *reinterpret_cast<uint4*>(dst + (size_t)x * v.dim + y) = reinterpret_cast<const uint4*>(src)[q];
+        }
+        const uint32_t* socc = reinterpret_cast<const uint32_t*>(src + (size_t)rows * per_row * 16);
+        uint32_t* docc = v.occ + ((size_t)td * v.dim + j.x0) * v.ow;
+        for (int q = tid; q < rows * v.ow; q += BLOCK) docc[q] = socc[q];
+    }
+    if (tid == 0) { v.tile_bbox[4 * td + 0] = j.x0; v.tile_bbox[4 * td + 1] = j.x1; v.tile_bbox[4 * td + 2] = j.ya; v.tile_bbox[4 * td + 3] = j.yb - 1; }
+}
+
+void launch_export_weights(const DevView& v, double* d_out, int n_global, hipStream_t s) {
+    (void)hipMemsetAsync(d_out, 0, (size_t)n_global * 8, s);
+    hipLaunchKernelGGL(export_weights_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, v.P, v.weight, v.global_id, d_out, n_global);
+}
+void launch_sources_to_T(int P, const int32_t* d_idx, int32_t* d_T, int32_t* d_did, hipStream_t s) {
+    hipLaunchKernelGGL(sources_to_T_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, P, d_idx, d_T, d_did);
+}
+void launch_gather_meta(const DevView& v, const int32_t* d_local, int n, int32_t* d_out, hipStream_t s) {
+    int tot = n * v.L * v.L;
+    hipLaunchKernelGGL(gather_meta_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, v, d_local, n, d_out);
+}
+void launch_pack(const DevView& v, const void* d_jobs, int n_jobs, void* d_buf, hipStream_t s) {
+    if (n_jobs) hipLaunchKernelGGL(pack_kernel, dim3(n_jobs), dim3(BLOCK), 0, s, v, static_cast<const PackJob*>(d_jobs), static_cast<unsigned char*>(d_buf));
+}
+void launch_unpack(const DevView& v, const ResampleBuffers& b, const void* d_jobs, int n_jobs, const void* d_buf, hipStream_t s) {
+    if (n_jobs) hipLaunchKernelGGL(unpack_kernel, dim3(n_jobs), dim3(BLOCK), 0, s, v, static_cast<const UnpackJob*>(d_jobs),
+                                   static_cast<const unsigned char*>(d_buf), b.pending_free, b.n_pending);
+    hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
+}
+
 // ---- host-side launch sequence --------------------------------------------------------------------------
 void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
                              int32_t* d_did, int32_t* d_err, hipStream_t s) {
@@ -332,7 +495,7 @@ void launch_resample_indices(int P, const double* d_w, double u, double spread, 
 }
 
 void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s) {
-    PairArgs pa{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs};
+    PairArgs pa{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err};
     hipLaunchKernelGGL(resample_pair_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, pa);
     GatherArgs ga{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight,
                   b.px2, b.py2, b.pth2, b.cov2, b.w2};

@@ -55,6 +55,17 @@ static int check_device_error(rbpf_handle* h) {
     return RBPF_OK;
 }
 
+template <typename T>
+static int scratch(rbpf_handle* h, T** ptr, size_t* cap, size_t n) {
+    if (*cap >= n) return RBPF_OK;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    size_t want = std::max<size_t>(n, 1024);
+    HIP_TRY(h, hipMalloc((void**)ptr, want * sizeof(T)));
+    *cap = want;
+    return RBPF_OK;
+}
+
 extern "C" {
 
 int rbpf_default_config(rbpf_config* c) {
@@ -246,6 +257,10 @@ int rbpf_destroy(rbpf_handle* h) {
     if (h->d_guess) hipFree(h->d_guess);
     if (h->d_prs) hipFree(h->d_prs);
     if (h->d_w) hipFree(h->d_w);
+    if (h->d_gT) hipFree(h->d_gT);
+    if (h->d_gidx) hipFree(h->d_gidx);
+    if (h->d_i32) hipFree(h->d_i32);
+    if (h->d_jobs) hipFree(h->d_jobs);
     if (h->h_pinned) hipHostFree(h->h_pinned);
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) for (int e = 0; e < 2; ++e) for (auto& ev : h->ring[k][e]) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -553,12 +568,143 @@ int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resam
     return RBPF_OK;
 }
 
-int rbpf_export_weights(rbpf_handle* h, void*, int32_t) { return fail(h, RBPF_ESTATE, "not built yet"); }
-int rbpf_resample_indices_global(rbpf_handle* h, const void*, int32_t, double, int32_t*, int32_t*) { return fail(h, RBPF_ESTATE, "not built yet"); }
-int rbpf_apply_resample_local(rbpf_handle* h, const int32_t*, const int32_t*) { return fail(h, RBPF_ESTATE, "not built yet"); }
-int64_t rbpf_packed_particle_bytes(rbpf_handle*) { return -1; }
-int rbpf_pack_particles(rbpf_handle* h, const int32_t*, int32_t, void*) { return fail(h, RBPF_ESTATE, "not built yet"); }
-int rbpf_unpack_particles(rbpf_handle* h, const int32_t*, int32_t, const void*) { return fail(h, RBPF_ESTATE, "not built yet"); }
+// ---- multi-GPU pieces: one handle per rank, the collectives are the caller's (RCCL) ---------------------------------
+int rbpf_set_global_ids(rbpf_handle* h, const int32_t* ids) {
+    if (!h || !ids) return RBPF_EINVAL;
+    HIP_TRY(h, hipMemcpyAsync(h->v.global_id, ids, (size_t)h->v.P * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RBPF_OK;
+}
+
+int rbpf_export_weights(rbpf_handle* h, void* d_global, int32_t n_global) {
+    if (!h || !d_global || n_global < h->v.P) return RBPF_EINVAL;
+    launch_export_weights(h->v, static_cast<double*>(d_global), n_global, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));        // the caller's collective may run on another stream
+    return RBPF_OK;
+}
+
+int rbpf_resample_indices_global(rbpf_handle* h, const void* d_global, int32_t n_global, double u, int32_t* idx_out,
+                                 int32_t* did_resample) {
+    if (!h || !d_global || !idx_out || !did_resample || n_global < 1) return RBPF_EINVAL;
+    if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
+    int rc = scratch(h, &h->d_gT, &h->d_gT_cap, (size_t)n_global);
+    if (rc) return rc;
+    rc = scratch(h, &h->d_gidx, &h->d_gidx_cap, (size_t)n_global);
+    if (rc) return rc;
+    launch_resample_indices(n_global, static_cast<const double*>(d_global), u, h->cfg.resample_spread, h->d_gT, h->d_gidx,
+                            h->rs.did, h->v.err, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(idx_out, h->d_gidx, (size_t)n_global * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(did_resample, h->rs.did, 4, hipMemcpyDeviceToHost, h->stream));
+    return check_device_error(h);
+}
+
+int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int32_t* new_global_id) {
+    if (!h || !new_src || !new_global_id) return RBPF_EINVAL;
+    DevView& v = h->v;
+    // sources must be sorted ascending with the arrivals (-1) last: duplicates of one ancestor are then adjacent
+    for (int j = 1; j < v.P; ++j) {
+        bool ok = new_src[j] < 0 ? true : (new_src[j - 1] >= 0 && new_src[j - 1] <= new_src[j]);
+        if (!ok) return fail(h, RBPF_EINVAL, "new_src must be sorted ascending with -1 entries last");
+    }
+    for (int j = 0; j < v.P; ++j) if (new_src[j] >= v.P) return fail(h, RBPF_EINVAL, "new_src out of range");
+    HIP_TRY(h, hipMemcpyAsync(h->rs.idx, new_src, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
+    h->prof_begin(2);
+    launch_sources_to_T(v.P, h->rs.idx, h->rs.T, h->rs.did, h->stream);
+    launch_resample_apply(v, h->rs, h->stream);
+    h->prof_end(2);
+    HIP_TRY(h, hipGetLastError());
+    swap_state_buffers(h);
+    HIP_TRY(h, hipMemcpyAsync(v.global_id, new_global_id, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
+    return check_device_error(h);
+}
+
+int32_t rbpf_pack_meta_width(rbpf_handle* h) { return h ? 2 + 6 * h->v.L * h->v.L : -1; }
+
+int64_t rbpf_packed_particle_bytes(rbpf_handle* h) {
+    if (!h) return -1;
+    const DevView& v = h->v;
+    return 128 + (int64_t)v.L * v.L * ((int64_t)v.dim * v.dim + (int64_t)v.dim * v.ow * 4);
+}
+
+// meta record of one particle: [0] tiles, [1] payload bytes / 16, then per lattice position (has, x0, x1, ya, yb, offset / 16)
+int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_buf, int64_t cap_bytes,
+                        int32_t* meta_out, int64_t* bytes_out) {
+    if (!h || n < 0 || !bytes_out || (n > 0 && (!local_idx || !d_buf || !meta_out))) return RBPF_EINVAL;
+    *bytes_out = 0;
+    if (n == 0) return RBPF_OK;
+    DevView& v = h->v;
+    const int LL = v.L * v.L, W = 2 + 6 * LL;
+    for (int i = 0; i < n; ++i) if (local_idx[i] < 0 || local_idx[i] >= v.P) return fail(h, RBPF_EINVAL, "local index out of range");
+    int rc = scratch(h, &h->d_i32, &h->d_i32_cap, (size_t)n * (1 + 5 * LL));
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_i32, local_idx, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    launch_gather_meta(v, h->d_i32, n, h->d_i32 + n, h->stream);
+    std::vector<int32_t> g((size_t)n * LL * 5);
+    HIP_TRY(h, hipMemcpyAsync(g.data(), h->d_i32 + n, g.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<PackJobHost> jobs;
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        int32_t* m = meta_out + (size_t)i * W;
+        const int64_t start = off;
+        jobs.push_back({local_idx[i], -1, 0, 0, 0, 0, (long long)off});
+        off += 128;
+        int nt = 0;
+        for (int pos = 0; pos < LL; ++pos) {
+            const int32_t* e = &g[((size_t)i * LL + pos) * 5];
+            int32_t* mm = m + 2 + 6 * pos;
+            mm[0] = mm[1] = mm[2] = mm[3] = mm[4] = mm[5] = 0;
+            if (e[0] < 0) continue;
+            ++nt;
+            mm[0] = 1;
+            int x0 = e[1], x1 = e[2], y0 = e[3], y1 = e[4];
+            if (x0 > x1 || y0 > y1) { mm[1] = 0; mm[2] = -1; mm[3] = 0; mm[4] = 0; mm[5] = (int32_t)((off - start) / 16); continue; }   // empty tile
+            int ya = y0 & ~15, yb = std::min((y1 | 15) + 1, v.dim);
+            mm[1] = x0; mm[2] = x1; mm[3] = ya; mm[4] = yb; mm[5] = (int32_t)((off - start) / 16);
+            jobs.push_back({local_idx[i], e[0], x0, x1, ya, yb, (long long)off});
+            int64_t bytes = (int64_t)(x1 - x0 + 1) * (yb - ya) + (int64_t)(x1 - x0 + 1) * v.ow * 4;
+            off += (bytes + 15) & ~(int64_t)15;
+        }
+        m[0] = nt; m[1] = (int32_t)((off - start) / 16);
+    }
+    if (off > cap_bytes) return fail(h, RBPF_ENOMEM, "pack buffer too small");
+    rc = scratch(h, &h->d_jobs, &h->d_jobs_cap, jobs.size() * sizeof(PackJobHost));
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(PackJobHost), hipMemcpyHostToDevice, h->stream));
+    launch_pack(v, h->d_jobs, (int)jobs.size(), d_buf, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *bytes_out = off;
+    return RBPF_OK;
+}
+
+// installs n received particles at the given local indices (after rbpf_apply_resample_local); weight <- 1.0 (main.py:77-78)
+int rbpf_unpack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, const void* d_buf, const int32_t* meta_in) {
+    if (!h || n < 0 || (n > 0 && (!local_idx || !d_buf || !meta_in))) return RBPF_EINVAL;
+    if (n == 0) return RBPF_OK;
+    DevView& v = h->v;
+    const int LL = v.L * v.L, W = 2 + 6 * LL;
+    std::vector<UnpackJobHost> jobs;
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (local_idx[i] < 0 || local_idx[i] >= v.P) return fail(h, RBPF_EINVAL, "local index out of range");
+        const int32_t* m = meta_in + (size_t)i * W;
+        jobs.push_back({local_idx[i], -1, 1, 0, 0, 0, 0, 0, (long long)off});
+        for (int pos = 0; pos < LL; ++pos) {
+            const int32_t* mm = m + 2 + 6 * pos;
+            jobs.push_back({local_idx[i], pos, mm[0], mm[1], mm[2], mm[3], mm[4], 0, (long long)(off + (int64_t)mm[5] * 16)});
+        }
+        off += (int64_t)m[1] * 16;
+    }
+    int rc = scratch(h, &h->d_jobs, &h->d_jobs_cap, jobs.size() * sizeof(UnpackJobHost));
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(UnpackJobHost), hipMemcpyHostToDevice, h->stream));
+    launch_unpack(v, h->rs, h->d_jobs, (int)jobs.size(), d_buf, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return check_device_error(h);
+}
 
 // ---- state access -----------------------------------------------------------------------------------------
 int rbpf_get_poses(rbpf_handle* h, double* out) {

@@ -92,6 +92,8 @@ struct rbpf_handle {
     double* d_last_xy = nullptr; float* d_tmp_sel = nullptr;
     double* d_match = nullptr; uint8_t* d_bad = nullptr; double* d_guess_full = nullptr;
     unsigned long long resample_draws = 0;
+    int32_t* d_gT = nullptr; size_t d_gT_cap = 0; int32_t* d_gidx = nullptr; size_t d_gidx_cap = 0;
+    int32_t* d_i32 = nullptr; size_t d_i32_cap = 0; unsigned char* d_jobs = nullptr; size_t d_jobs_cap = 0;
     // profiling: a ring of HIP-event pairs per kernel family, recorded on the handle's stream
     static const int N_KERN = 5, RING = 512;        // 0 ray-cast windows, 1 propose/weight, 2 resample, 3 match, 4 ray setup
     std::vector<hipEvent_t> ring[N_KERN][2];
@@ -115,6 +117,13 @@ void launch_imu_update(const DevView& v, int model, double d0, double d1, double
 void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
                              int32_t* d_did, int32_t* d_err, hipStream_t s);
 void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s);
+void launch_export_weights(const DevView& v, double* d_out, int n_global, hipStream_t s);
+void launch_sources_to_T(int P, const int32_t* d_idx, int32_t* d_T, int32_t* d_did, hipStream_t s);
+void launch_gather_meta(const DevView& v, const int32_t* d_local, int n, int32_t* d_out, hipStream_t s);
+void launch_pack(const DevView& v, const void* d_jobs, int n_jobs, void* d_buf, hipStream_t s);
+void launch_unpack(const DevView& v, const ResampleBuffers& b, const void* d_jobs, int n_jobs, const void* d_buf, hipStream_t s);
+struct PackJobHost { int32_t particle, tile, x0, x1, ya, yb; long long off; };
+struct UnpackJobHost { int32_t particle, pos, has, x0, x1, ya, yb, pad; long long off; };
 void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s);
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s);
