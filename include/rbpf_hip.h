@@ -52,7 +52,7 @@ typedef struct rbpf_handle rbpf_handle;
 typedef struct rbpf_config {
     int32_t n_particles;      /* P: particles held by this handle (main.py:44 NUM_PARTICLES)      */
     int32_t n_samples;        /* K: proposal samples per particle (robot.py:17, 30)               */
-    int32_t max_beams;        /* upper bound on beams per scan (<= 8191)                          */
+    int32_t max_beams;        /* upper bound on beams per scan (<= 4095)                          */
     int32_t tile_len_m;       /* tile edge in metres (hybridmap.py:68, 40)                        */
     double  cell_size;        /* metres per cell (hybridmap.py:67, 0.05)                          */
     int32_t lattice_radius;   /* tiles addressable per axis: -R..R (default 3 => +-140 m)         */

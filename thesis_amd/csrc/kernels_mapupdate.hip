@@ -43,20 +43,20 @@ namespace rbpf {
 #define BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 static const int MU_BLOCK = 512;       // 8 waves per particle
-static const int NB_MAX = 2304;        // bucket ids per window
-static const int EV_TOT = 6144;        // event slots per window
-static const int CHUNK = 32;           // ray steps per work item of the walk
+static const int NB_MAX = 1536;        // bucket ids per window (flagged cells beyond it take the membership-scan path)
+static const int EV_TOT = 5120;        // event slots per window
+static const int CHUNK = 16;           // ray steps per work item of the walk
 
 __host__ __device__ inline int mu_nb(int B) { int nb = 2 * B; return nb < NB_MAX ? nb : NB_MAX; }
-// chunk table entries: every ray has at most ceil((WIN + 2) / CHUNK) = 5 chunks in a window; the same memory later
+// chunk table entries: every ray has at most ceil((WIN + 2) / CHUNK) = 9 chunks in a window; the same memory later
 // holds the two replay work lists (NB deep buckets + the overflow list)
-__host__ __device__ inline int mu_chunk_cap(int B) { int a = 5 * B, b = 2 * mu_nb(B) + 64; int c = a > b ? a : b; return (c + 7) & ~7; }
+__host__ __device__ inline int mu_chunk_cap(int B) { int a = 9 * B, b = 2 * mu_nb(B) + 64; int c = a > b ? a : b; return (c + 7) & ~7; }
 
 size_t raycast_lds_bytes(int B) {
     size_t nb = mu_nb(B);
     size_t bpad = (size_t)((B + 3) & ~3);
     size_t bytes = (size_t)WIN * WIN / 2 * 4 + (size_t)WIN * WIN / 32 * 4 + (size_t)WIN * WIN / 32 * 2 + (size_t)EV_TOT * 2 + nb * 2 +
-                   (size_t)mu_chunk_cap(B) * 2 + 2 * (WIN + 8) * 2 + bpad * 4 + bpad * 2 * 2 + (size_t)((B + 15) & ~15);
+                   (size_t)mu_chunk_cap(B) * 2 + 2 * (WIN + 8) * 2 + bpad * 4 + bpad * 2 * 2 + 256 + (size_t)((B + 15) & ~15) + ((nb + 15) & ~(size_t)15);
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -69,6 +69,7 @@ struct MuLds {
     uint16_t* fpre;   // [WIN*WIN/32] flagged cells before each flag word (bucket id = rank in cell order)
     uint16_t* bev;    // [EV_TOT] (beam << 3) | rank; bucket id at [id*cap, (id+1)*cap)
     uint16_t* bcell;  // [NB] local cell index of bucket id
+    uint8_t*  oldv;   // [NB] value of the flagged cell before this scan (from the prefetched words)
     uint16_t* chunk;  // [CH_CAP] walk work items (beam << 3) | chunk; later the replay work lists
     int16_t*  lutx;   // [WIN+8]
     int16_t*  luty;
@@ -76,6 +77,7 @@ struct MuLds {
     int16_t*  seg_lo; // [B] first / last step of the ray inside the current window
     int16_t*  seg_hi;
     uint8_t*  r_info; // [B]
+    uint32_t* dummy;  // [64] per-lane sink for the atomics of skipped steps
 };
 
 __device__ __forceinline__ uint32_t cnt16_get(const uint32_t* cnt, int c) { return (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu; }
@@ -85,6 +87,16 @@ __device__ __forceinline__ bool flag_get(const uint32_t* flag, int c) { return (
 // same-tile test of hybridmap.py:141 (m.is_in_map(nearby_pos) with m = tile of the end cell)
 __device__ __forceinline__ bool same_tile(const DevView& v, int xa, int ya, int xb, int yb) {
     return lut_lat(lut_at(v, xa)) == lut_lat(lut_at(v, xb)) && lut_lat(lut_at(v, ya)) == lut_lat(lut_at(v, yb));
+}
+
+// wave-level reductions (all 64 lanes take part): one LDS atomic per wave instead of one per lane
+__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ int wave_sum(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {   // exclusive prefix sum over the wave
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+    return incl - v;
 }
 
 // first j with minor offset >= m (m >= 1, dmin > 0), 32-bit (2*dmaj*m < 2^31 for rays shorter than a tile)
@@ -206,7 +218,9 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     s.r_end = reinterpret_cast<int32_t*>(s.luty + (WIN + 8));
     s.seg_lo = reinterpret_cast<int16_t*>(s.r_end + BPAD);
     s.seg_hi = s.seg_lo + BPAD;
-    s.r_info = reinterpret_cast<uint8_t*>(s.seg_hi + BPAD);
+    s.dummy = reinterpret_cast<uint32_t*>(s.seg_hi + BPAD);
+    s.r_info = reinterpret_cast<uint8_t*>(s.dummy + 64);
+    s.oldv = s.r_info + ((v.B + 15) & ~15);
 
     __shared__ double s_c, s_s, s_px, s_py;
     __shared__ int s_x0, s_y0, s_skip;
@@ -303,10 +317,14 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             }
             s.r_info[b] = (uint8_t)info;
         }
-        if (my_cells) {
-            atomicAdd(&s_cells, my_cells);
-            atomicMin(&s_fan[0], fx0); atomicMax(&s_fan[1], fx1);
-            atomicMin(&s_fan[2], fy0); atomicMax(&s_fan[3], fy1);
+        {
+            const int ws = wave_sum((int)my_cells);                      // < 64 * 16 rays * 2^16 steps
+            fx0 = wave_min(fx0); fx1 = wave_max(fx1); fy0 = wave_min(fy0); fy1 = wave_max(fy1);
+            if ((tid & 63) == 0) {
+                atomicAdd(&s_cells, (unsigned long long)ws);
+                atomicMin(&s_fan[0], fx0); atomicMax(&s_fan[1], fx1);
+                atomicMin(&s_fan[2], fy0); atomicMax(&s_fan[3], fy1);
+            }
         }
     }
     __syncthreads();
@@ -364,12 +382,28 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     s_bb[0] = INT_MAX; s_bb[1] = -1; s_bb[2] = INT_MAX; s_bb[3] = -1;
                 }
             }
+            // prefetch this thread's 32-cell group of the window (128 rows x 4 groups = 512 threads): the HBM read latency
+            // overlaps the LDS phases, the read-modify-write at the end only stores
+            const int g_lx = tid / (WIN / 32), g_ly = (tid % (WIN / 32)) * 32;
+            const int g_row = wx0 + g_lx, g_col = wy0 + g_ly;
+            const bool g_in = g_row < v.dim && g_col < v.dim;
+            const int g_nw = g_in ? min(8, (v.dim - g_col) >> 2) : 0;    // words inside the row (dim is a multiple of 16)
+            uint32_t* const g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)(g_in ? g_row : 0) * v.dim + (g_in ? g_col : 0));
+            uint32_t pre[8];
+            if (g_nw == 8) {
+                const uint4 a0 = reinterpret_cast<const uint4*>(g_ptr)[0], a1 = reinterpret_cast<const uint4*>(g_ptr)[1];
+                pre[0] = a0.x; pre[1] = a0.y; pre[2] = a0.z; pre[3] = a0.w; pre[4] = a1.x; pre[5] = a1.y; pre[6] = a1.z; pre[7] = a1.w;
+            } else {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) pre[w] = w < g_nw ? g_ptr[w] : 0u;
+            }
             BAR_LDS();
             STAMP(1);
 
             // ---- phase 1: flag the cells that receive an "occupied" or "nearby" hit; clip every ray to the window ----
-            for (int b = tid; b < v.B; b += MU_BLOCK) {
-                const int info = s.r_info[b];
+            for (int b0 = 0; b0 < v.B; b0 += MU_BLOCK) {          // wave-uniform trip count (the loop body uses shuffles)
+                const int b = b0 + tid;
+                const int info = b < v.B ? s.r_info[b] : 0;
                 int jlo = 1, jhi = 0;
                 if (info & RI_VALID) {
                     int x1, y1;
@@ -409,15 +443,21 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                         }
                     }
                 }
-                // chunks of up to CHUNK steps, one table entry each: (beam << 3) | chunk index
-                if (jlo <= jhi) {
+                // chunks of up to CHUNK steps, one table entry each: (beam << 4) | chunk index; the table space of a
+                // wave is claimed with one atomic
+                const int nch = jlo <= jhi ? (jhi - jlo) / CHUNK + 1 : 0;
+                const int wpre = wave_excl_scan(nch, lane);
+                int wbase = 0;
+                if (lane == 63) wbase = atomicAdd(&s_nchunk, wpre + nch);
+                wbase = __shfl(wbase, 63, 64);
+                if (nch) {
                     s.seg_lo[b] = (int16_t)jlo; s.seg_hi[b] = (int16_t)jhi;
-                    int nch = (jhi - jlo) / CHUNK + 1;
-                    int base = atomicAdd(&s_nchunk, nch);
-                    for (int k = 0; k < nch; ++k) if (base + k < CH_CAP) s.chunk[base + k] = (uint16_t)((b << 3) | k);
+                    const int base = wbase + wpre;
+                    for (int k = 0; k < nch; ++k) if (base + k < CH_CAP) s.chunk[base + k] = (uint16_t)((b << 4) | k);
                 }
             }
             BAR_LDS();
+            STAMP(7);
             // rank of every flagged cell among the window's flagged cells = its bucket id (cell order)
             {
                 const int w = tid;                          // one flag word per thread (WIN*WIN/32 == MU_BLOCK)
@@ -432,7 +472,17 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 s.fpre[w] = (uint16_t)excl;
                 if (tid == MU_BLOCK - 1) s_nflag = excl + pc;
                 uint32_t bb = bits; int id = excl;
-                while (bb) { int bit = __ffs(bb) - 1; bb &= bb - 1; if (id < NB) s.bcell[id] = (uint16_t)(w * 32 + bit); ++id; }
+                while (bb) {                                  // flag word w covers exactly this thread's prefetched group
+                    int bit = __ffs(bb) - 1; bb &= bb - 1;
+                    if (id < NB) {
+                        s.bcell[id] = (uint16_t)(w * 32 + bit);
+                        uint32_t wsel = pre[0];
+#pragma unroll
+                        for (int q = 1; q < 8; ++q) wsel = (bit >> 2) == q ? pre[q] : wsel;
+                        s.oldv[id] = (uint8_t)((wsel >> (8 * (bit & 3))) & 0xFFu);
+                    }
+                    ++id;
+                }
             }
             BAR_LDS();
             // event slots are shared out evenly: few flagged cells (a near wall under dense beams) get deep buckets
@@ -447,12 +497,12 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 if (s_nchunk > CH_CAP && tid == 0) atomicCAS(v.err, 0, RBPF_ENOMEM);   // cannot happen: B*5 entries
                 for (int q = tid; q < nchunk; q += MU_BLOCK) {
                     const int desc = s.chunk[q];
-                    const int b = desc >> 3;
+                    const int b = desc >> 4;
                     const int info = s.r_info[b];
                     int x1, y1;
                     unpack_end(s.r_end[b], x0, y0, x1, y1);
                     const Ray r = ray_make(x0, y0, x1, y1);
-                    const int jlo = s.seg_lo[b] + (desc & 7) * CHUNK;
+                    const int jlo = s.seg_lo[b] + (desc & 15) * CHUNK;
                     const int jhi = min((int)s.seg_hi[b], jlo + CHUNK - 1);
                     const int m0 = r.steep ? y0 : x0, n0 = r.steep ? x0 : y0;
                     const int smaj = r.steep ? r.sy : r.sx, smin = r.steep ? r.sx : r.sy;
@@ -461,36 +511,50 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     int m = ray_minor_at(r, jlo);
                     int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;   // hybridmap.py:289-300 invariant
                     for (int j4 = jlo; j4 <= jhi; j4 += 4) {
-                        int c[4]; uint32_t h[4];
+                        // Branch-free on purpose: four cells' index maps, counters and atomics are issued back to back
+                        // (behind a branch the compiler drains the LDS queue after every access).  Steps past the
+                        // chunk end repeat the last cell and add 0 to a per-lane dummy word.
+                        int c[4]; uint32_t h[4]; int lxv[4], lyv[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {                     // four cells: index math + counter reads
+                        for (int u = 0; u < 4; ++u) {
                             const int j = j4 + u;
-                            const int maj = m0 + smaj * j, mnr = n0 + smin * m;
-                            const int ix = (r.steep ? mnr : maj) - gxa, iy = (r.steep ? maj : mnr) - gya;
-                            if (D >= 0) { ++m; D -= 2 * r.dmaj; }
-                            D += 2 * r.dmin;
-                            const bool in = j <= jhi && (unsigned)ix < (unsigned)nx_ && (unsigned)iy < (unsigned)ny_;
-                            c[u] = in ? s.lutx[in ? ix : 0] * WIN + s.luty[in ? iy : 0] : -1;
+                            const bool live = j <= jhi;
+                            const int maj = m0 + smaj * (live ? j : jhi), mnr = n0 + smin * m;
+                            int ix = (r.steep ? mnr : maj) - gxa, iy = (r.steep ? maj : mnr) - gya;
+                            if (live) { if (D >= 0) { ++m; D -= 2 * r.dmaj; } D += 2 * r.dmin; }
+                            ix = min(max(ix, 0), nx_ - 1); iy = min(max(iy, 0), ny_ - 1);
+                            lxv[u] = s.lutx[ix]; lyv[u] = s.luty[iy];
+                            c[u] = live ? 0 : -1;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) h[u] = c[u] >= 0 ? (s.cnt[c[u] >> 1] >> ((c[u] & 1) * 16)) & 0xFFFFu : 0u;
+                        for (int u = 0; u < 4; ++u) {
+                            const int cc = lxv[u] * WIN + lyv[u];
+                            h[u] = (s.cnt[cc >> 1] >> ((cc & 1) * 16)) & 0xFFFFu;
+                            c[u] = c[u] < 0 ? -1 : cc;
+                        }
+                        uint32_t* ap[4]; uint32_t av[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             // an unflagged cell only needs min(n, sat) hits: max(v + n*emp, vmin) is vmin for every
-                            // n >= sat.  The plain read above is a broadcast; skipping spares the serialised
-                            // same-address atomics of the cells next to the sensor, which every ray crosses.
-                            if (c[u] < 0 || (h[u] - (uint32_t)sat < 0x8000u - (uint32_t)sat)) { h[u] = 0; continue; }
-                            const int sh = (c[u] & 1) * 16;
-                            h[u] = (atomicAdd(&s.cnt[c[u] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                            // n >= sat; skipping spares the serialised same-address atomics of the cells next to the
+                            // sensor, which every ray crosses
+                            const bool need = c[u] >= 0 && !(h[u] - (uint32_t)sat < 0x8000u - (uint32_t)sat);
+                            ap[u] = need ? &s.cnt[c[u] >> 1] : &s.dummy[lane];
+                            av[u] = need ? 1u << ((c[u] & 1) * 16) : 0u;
+                            if (!need) c[u] = -1;
                         }
 #pragma unroll
+                        for (int u = 0; u < 4; ++u) h[u] = atomicAdd(ap[u], av[u]);
+#pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            if (!(h[u] & 0x8000u)) continue;  // flagged: the counter value is the slot in the cell's bucket
+                            if (c[u] < 0) continue;
+                            const uint32_t hv = (h[u] >> ((c[u] & 1) * 16)) & 0xFFFFu;
+                            if (!(hv & 0x8000u)) continue;    // flagged: the counter value is the slot in the cell's bucket
                             const int cc = c[u], j = j4 + u;
                             const int id = s.fpre[cc >> 5] + __popc(s.flag[cc >> 5] & ((1u << (cc & 31)) - 1u));
                             const int rem = r.n - 1 - j;
                             const int rank = (rem == 0) ? (occ ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
-                            int pos = (int)(h[u] & 0x7FFFu);
+                            int pos = (int)(hv & 0x7FFFu);
                             if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | rank);
                             if (near_ok && rem == 1) {
                                 const int sh = (cc & 1) * 16;
@@ -513,8 +577,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 const int m = id < nbk ? (int)(cnt16_get(s.cnt, c) & 0x7FFFu) : INT_MAX;
                 if (m > cap) { slowc[atomicAdd(&s_nslow, 1)] = (uint16_t)c; continue; }
                 if (m > 16) { bigc[atomicAdd(&s_nbig, 1)] = (uint16_t)id; continue; }
-                const int lx = c / WIN, ly = c % WIN;
-                int val = tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)];
+                int val = (int)(int8_t)s.oldv[id];
                 // replay in ascending (beam, rank): bitonic sorting network over registers, then a sequential fold
                 const uint16_t* evp = s.bev + id * cap;
                 if (m <= 8) val = replay_sorted<8>(evp, m, val, v.cc);
@@ -561,8 +624,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                         if ((lane & (2 * off - 1)) == 0) f = caf_then(f, g);
                     }
                     if (lane == 0) {
-                        const int lx = c / WIN, ly = c % WIN;
-                        int val = caf_apply(f, (int)tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)]);
+                        int val = caf_apply(f, (int)(int8_t)s.oldv[id]);
                         cnt16_set(s.cnt, c, 0x8000u | ((uint32_t)val & 0xFFu));
                     }
                 }
@@ -589,8 +651,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             int my_written = 0;
             int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
             {
-                const int lx = tid / (WIN / 32), g = tid % (WIN / 32);       // 128 rows x 4 groups = 512 threads
-                const int ly = g * 32;
+                const int lx = g_lx, ly = g_ly;
                 const uint4* c4 = reinterpret_cast<const uint4*>(s.cnt + ((lx * WIN + ly) >> 1));
                 uint32_t n[16];
                 {
@@ -601,22 +662,12 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 uint32_t any = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) any |= n[k];
-                const int row = wx0 + lx, col = wy0 + ly;
-                if (any && row < v.dim && col < v.dim) {
-                    uint32_t* gp = reinterpret_cast<uint32_t*>(tile_base + (size_t)row * v.dim + col);
-                    const int nw = min(8, (v.dim - col) >> 2);               // words inside the row (dim is a multiple of 16)
-                    uint32_t wd[8];
-                    if (nw == 8) {
-                        const uint4 a0 = reinterpret_cast<const uint4*>(gp)[0], a1 = reinterpret_cast<const uint4*>(gp)[1];
-                        wd[0] = a0.x; wd[1] = a0.y; wd[2] = a0.z; wd[3] = a0.w; wd[4] = a1.x; wd[5] = a1.y; wd[6] = a1.z; wd[7] = a1.w;
-                    } else {
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) wd[w] = w < nw ? gp[w] : 0u;
-                    }
+                const int row = g_row, col = g_col;
+                if (any && g_in) {
                     uint32_t occ = 0;
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {
-                        uint32_t word = wd[w];
+                        uint32_t word = pre[w];
                         const uint32_t cw0 = n[2 * w], cw1 = n[2 * w + 1];
                         if (cw0 | cw1) {
                             const uint32_t nn[4] = {cw0 & 0xFFFFu, cw0 >> 16, cw1 & 0xFFFFu, cw1 >> 16};
@@ -631,7 +682,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                                     by0 = min(by0, col + 4 * w + k); by1 = max(by1, col + 4 * w + k);
                                 }
                             }
-                            if (w < nw) gp[w] = word;
+                            if (w < g_nw) g_ptr[w] = word;
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -642,10 +693,14 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 }
             }
             STAMP(5);
-            if (my_written) {
-                atomicAdd(&s_written, my_written);
-                atomicMin(&s_bb[0], bx0); atomicMax(&s_bb[1], bx1);
-                atomicMin(&s_bb[2], by0); atomicMax(&s_bb[3], by1);
+            {
+                const int ww = wave_sum(my_written);
+                bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
+                if (lane == 0 && ww) {
+                    atomicAdd(&s_written, ww);
+                    atomicMin(&s_bb[0], bx0); atomicMax(&s_bb[1], bx1);
+                    atomicMin(&s_bb[2], by0); atomicMax(&s_bb[3], by1);
+                }
             }
             BAR_LDS();
             STAMP(6);
@@ -667,7 +722,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
         if (s_tot_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_tot_written);
         if (s_tot_slow) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)s_tot_slow);
 #ifdef RBPF_STAMPS
-        for (int k = 0; k < 7; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
 #endif
     }
 }

@@ -111,7 +111,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     const rbpf_config& c = *cfg;
     if (c.n_particles < 1) return fail(nullptr, RBPF_EINVAL, "n_particles must be >= 1");
     if (c.n_samples < 1 || c.n_samples > 32) return fail(nullptr, RBPF_EINVAL, "n_samples must be in 1..32");
-    if (c.max_beams < 1 || c.max_beams > 8191) return fail(nullptr, RBPF_EINVAL, "max_beams must be in 1..8191");
+    if (c.max_beams < 1 || c.max_beams > 4095) return fail(nullptr, RBPF_EINVAL, "max_beams must be in 1..4095");
     if (c.lattice_radius < 0 || c.lattice_radius > 3) return fail(nullptr, RBPF_EINVAL, "lattice_radius must be in 0..3");
     if (!(c.cell_size > 0) || c.tile_len_m < 1) return fail(nullptr, RBPF_EINVAL, "cell_size/tile_len_m");   // gridmap.py:29
     const int dim = (int)llround((double)c.tile_len_m / c.cell_size);                                        // gridmap.py:31
@@ -322,7 +322,8 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.cells_gathered = st[ST_GATHERS]; c.slow_cells = st[ST_SLOW_CELLS];
     c.resample_copies = st[ST_COPIES]; c.bytes_copied = st[ST_COPY_BYTES];
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
-    for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];      // phase cycle sums of a -DRBPF_STAMPS diagnostic build
+    for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];
+    c.cells_gathered = st[15];                                  // eighth stamp slot of a diagnostic build      // phase cycle sums of a -DRBPF_STAMPS diagnostic build
     if (h->profiling) {
         double* dst[4] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match};
         for (int k = 0; k < 4; ++k) {

@@ -13,8 +13,8 @@ r.e.set_profiling(True)
 for _ in range(8):
     r.step()
 c = r.e.counters()
-st = np.array(c["stamps"], dtype=np.float64)
-names = ["setup", "P0 clear", "P1 flag+ids", "P2 walk", "P3a apply", "P3b+c replay", "P4"]
+st = np.array(list(c["stamps"]) + [c["cells_gathered"]], dtype=np.float64)
+names = ["setup", "P0 clear+lut", "P1b rank+oldv", "P2 walk", "P3 replay", "P4 rmw", "end barrier", "P1a flag+clip"]
 print("raycast ms mean", r.e.kernel_ms("raycast").mean())
 for n, v in zip(names, st):
     print(f"{n:14s} {v/st.sum()*100:6.2f} %   {v/(8*P):12.0f} cycles/particle")
