@@ -124,6 +124,20 @@ __device__ __forceinline__ Caf caf_then(Caf f, Caf g) {          // g after f
 }
 __device__ __forceinline__ int caf_apply(Caf f, int x) { int t = x + f.a; t = t < f.lo ? f.lo : t; return t > f.hi ? f.hi : t; }
 
+// a hit on a flagged cell: the counter value returned by the atomic is the event's slot in the cell's bucket
+__device__ __forceinline__ void walk_flagged(const MuLds& s, int cc, uint32_t hv, int b, int rem, bool occ, bool near_ok,
+                                             int nbk, int cap) {
+    const int id = s.fpre[cc >> 5] + __popc(s.flag[cc >> 5] & ((1u << (cc & 31)) - 1u));
+    const int rank = (rem == 0) ? (occ ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+    int pos = (int)(hv & 0x7FFFu);
+    if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | rank);
+    if (near_ok && rem == 1) {
+        const int sh = (cc & 1) * 16;
+        pos = (int)((atomicAdd(&s.cnt[cc >> 1], 1u << sh) >> sh) & 0x7FFFu);
+        if (id < nbk && pos < cap) s.bev[id * cap + pos] = (uint16_t)((b << 3) | EV_NEAR);
+    }
+}
+
 // One lane replays a bucket of up to N events: bitonic sorting network on registers (padded with 0xFFFF), then the
 // clamped adds in ascending (beam, rank) order.
 template <int N>
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     __shared__ int s_x0, s_y0, s_skip;
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];                       // ray fan bounding box: gx min, gx max, gy min, gy max
-    __shared__ int s_nflag, s_bb[4], s_written, s_nslow, s_nbig, s_nchunk, s_wsum[MU_BLOCK / 64], s_tot_written, s_tot_slow;
+    __shared__ int s_nflag, s_bb[4], s_written, s_nslow, s_nbig, s_nchunk, s_ident, s_wsum[MU_BLOCK / 64], s_tot_written, s_tot_slow;
     static_assert(WIN * WIN / 32 == MU_BLOCK, "one flag word per thread");
     __shared__ unsigned long long s_cells;
 
@@ -369,14 +383,25 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             const int wx0 = wxi * WIN, wy0 = wyi * WIN;
             const int gxa = gwx[wxi], gxb = gwx[wxi + 1], gya = gwy[wyi], gyb = gwy[wyi + 1];   // [gxa,gxb) x [gya,gyb)
             const int nx_ = gxb - gxa, ny_ = gyb - gya;
+            if (tid == 0) s_ident = 1;
             BAR_LDS();                                     // previous window fully done with LDS
             // ---- phase 0: clear the counters, local index maps ----------------------------------------------------
             {
                 uint4* c4 = reinterpret_cast<uint4*>(s.cnt);
                 for (int i = tid; i < WIN * WIN / 8; i += MU_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
                 for (int i = tid; i < WIN * WIN / 32; i += MU_BLOCK) s.flag[i] = 0;
-                for (int i = tid; i < nx_ && i < WIN + 8; i += MU_BLOCK) s.lutx[i] = (int16_t)(lut_cidx(lut_at(v, gxa + i)) - wx0);
-                for (int i = tid; i < ny_ && i < WIN + 8; i += MU_BLOCK) s.luty[i] = (int16_t)(lut_cidx(lut_at(v, gya + i)) - wy0);
+                // local index maps; `s_ident` stays 1 when both are pure offsets (no off-by-one glitch of the reference's
+                // index formula inside this window: always the case on the positive side of a tile)
+                for (int i = tid; i < nx_ && i < WIN + 8; i += MU_BLOCK) {
+                    const int val = lut_cidx(lut_at(v, gxa + i)) - wx0;
+                    s.lutx[i] = (int16_t)val;
+                    if (val != lut_cidx(lut_at(v, gxa)) - wx0 + i) s_ident = 0;
+                }
+                for (int i = tid; i < ny_ && i < WIN + 8; i += MU_BLOCK) {
+                    const int val = lut_cidx(lut_at(v, gya + i)) - wy0;
+                    s.luty[i] = (int16_t)val;
+                    if (val != lut_cidx(lut_at(v, gya)) - wy0 + i) s_ident = 0;
+                }
                 if (tid == 0) {
                     s_nflag = 0; s_written = 0; s_nslow = 0; s_nbig = 0; s_nchunk = 0;
                     s_bb[0] = INT_MAX; s_bb[1] = -1; s_bb[2] = INT_MAX; s_bb[3] = -1;
@@ -494,6 +519,8 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             // ---- phase 2: walk the clipped rays, CHUNK steps per work item, four steps in flight ------------------------
             {
                 const int nchunk = min(s_nchunk, CH_CAP);
+                const bool ident = s_ident != 0;
+                const int offx = s.lutx[0], offy = s.luty[0];             // local index of the window's first global column
                 if (s_nchunk > CH_CAP && tid == 0) atomicCAS(v.err, 0, RBPF_ENOMEM);   // cannot happen: B*5 entries
                 for (int q = tid; q < nchunk; q += MU_BLOCK) {
                     const int desc = s.chunk[q];
@@ -510,6 +537,53 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     const bool near_ok = info & RI_NEAR;
                     int m = ray_minor_at(r, jlo);
                     int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;   // hybridmap.py:289-300 invariant
+                    if (ident) {
+                        // identity window: the local cell index advances by constants, no index-map reads
+                        const int lx0 = (r.steep ? n0 + smin * m : m0 + smaj * jlo) - gxa + offx;
+                        const int ly0 = (r.steep ? m0 + smaj * jlo : n0 + smin * m) - gya + offy;
+                        int c = lx0 * WIN + ly0;
+                        const int dmajc = smaj * (r.steep ? 1 : WIN), dminc = smin * (r.steep ? WIN : 1);
+                        const bool check_sat = (desc & 15) < 2 && s.seg_lo[b] < 2 * CHUNK;    // only near the sensor
+                        int j = jlo;
+                        for (; j + 3 <= jhi; j += 4) {
+                            int cc[4]; uint32_t h[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                cc[u] = c;
+                                if (D >= 0) { c += dminc; D -= 2 * r.dmaj; }
+                                D += 2 * r.dmin; c += dmajc;
+                            }
+                            if (check_sat) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) h[u] = reinterpret_cast<const uint16_t*>(s.cnt)[cc[u]];
+                            }
+                            uint32_t* ap[4]; uint32_t av[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool skip = check_sat && (h[u] - (uint32_t)sat < 0x8000u - (uint32_t)sat);
+                                ap[u] = skip ? &s.dummy[lane] : &s.cnt[cc[u] >> 1];
+                                av[u] = skip ? 0u : 1u << ((cc[u] & 1) * 16);
+                                if (skip) cc[u] = -1;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) h[u] = atomicAdd(ap[u], av[u]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (cc[u] < 0) continue;
+                                const uint32_t hv = (h[u] >> ((cc[u] & 1) * 16)) & 0xFFFFu;
+                                if (hv & 0x8000u) walk_flagged(s, cc[u], hv, b, r.n - 1 - (j + u), occ, near_ok, nbk, cap);
+                            }
+                        }
+                        for (; j <= jhi; ++j) {
+                            const int c1 = c;
+                            if (D >= 0) { c += dminc; D -= 2 * r.dmaj; }
+                            D += 2 * r.dmin; c += dmajc;
+                            const int sh = (c1 & 1) * 16;
+                            const uint32_t hv = (atomicAdd(&s.cnt[c1 >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                            if (hv & 0x8000u) walk_flagged(s, c1, hv, b, r.n - 1 - j, occ, near_ok, nbk, cap);
+                        }
+                        continue;
+                    }
                     for (int j4 = jlo; j4 <= jhi; j4 += 4) {
                         // Branch-free on purpose: four cells' index maps, counters and atomics are issued back to back
                         // (behind a branch the compiler drains the LDS queue after every access).  Steps past the
