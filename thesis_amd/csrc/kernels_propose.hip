@@ -159,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
                     double gx = (s_c[k0 + k] * x + (-s_s[k0 + k]) * y) + s_g[k0 + k][0];   // lidar.py:123
                     double gy = (s_s[k0 + k] * x + s_c[k0 + k] * y) + s_g[k0 + k][1];
                     int val;
-                    if (lookup_cell(v, s_tab, gx, gy, val)) acc[k] += val;
+                    if (lookup_cell_fast(v, s_tab, gx, gy, val)) acc[k] += val;
                 }
             }
         }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void bad_weight_kernel(DevView v, const uint
         const double x = v.bx[b], y = v.by[b];
         double gx = (cs * x + (-sn) * y) + tx, gy = (sn * x + cs * y) + ty;
         int val;
-        if (lookup_cell(v, s_tab, gx, gy, val)) acc += val;
+        if (lookup_cell_fast(v, s_tab, gx, gy, val)) acc += val;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((tid & 63) == 0) atomicAdd(&s_sum, acc);

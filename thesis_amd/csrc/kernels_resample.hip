@@ -239,15 +239,22 @@ struct CopyArgs {
 
 __device__ __forceinline__ void copy_rows(int8_t* dst, const int8_t* src, int dim, int x0, int x1, int y0, int y1,
                                           int tid) {
-    // rows x0..x1, columns rounded out to 16-byte groups; src == nullptr zero-fills
+    // rows x0..x1, columns rounded out to 16-byte groups; src == nullptr zero-fills; four loads in flight per thread
     const int ya = y0 & ~15, yb = min((y1 | 15) + 1, dim);
     const int per_row = (yb - ya) / 16;
     const int n = (x1 - x0 + 1) * per_row;
-    for (int q = tid; q < n; q += BLOCK) {
-        int x = x0 + q / per_row, y = ya + (q % per_row) * 16;
-        size_t off = (size_t)x * dim + y;
-        uint4 val = src ? *reinterpret_cast<const uint4*>(src + off) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst + off) = val;
+    for (int q0 = tid; q0 < n; q0 += 4 * BLOCK) {
+        uint4 val[4]; size_t off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = q0 + k * BLOCK;
+            const int qq = q < n ? q : q0;
+            off[k] = (size_t)(x0 + qq / per_row) * dim + ya + (qq % per_row) * 16;
+            val[k] = src ? *reinterpret_cast<const uint4*>(src + off[k]) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q0 + k * BLOCK < n) *reinterpret_cast<uint4*>(dst + off[k]) = val[k];
     }
 }
 
@@ -258,7 +265,7 @@ __device__ __forceinline__ void copy_occ_rows(uint32_t* dst, const uint32_t* src
 }
 
 __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
-    __shared__ int s_item, s_tile;
+    __shared__ int s_item, s_tile, s_ts[49], s_td[49];
     const DevView& v = a.v;
     const int tid = threadIdx.x;
     const int LL = v.L * v.L;
@@ -267,12 +274,14 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
         __syncthreads();
         if (tid == 0) s_item = atomicAdd(&a.n_jobs[1], 1);
         __syncthreads();
-        const int item = s_item;
-        if (item >= a.n_jobs[0] * LL) return;
-        const int job = item / LL, pos = item % LL;
+        const int job = s_item;
+        if (job >= a.n_jobs[0]) return;
         const int src_slot = a.jobs[2 * job], dst_slot = a.jobs[2 * job + 1];
-        const int ts = v.tile_tab[(size_t)src_slot * LL + pos];
-        int td = v.tile_tab[(size_t)dst_slot * LL + pos];
+        if (tid < LL) { s_ts[tid] = v.tile_tab[(size_t)src_slot * LL + tid]; s_td[tid] = v.tile_tab[(size_t)dst_slot * LL + tid]; }
+        __syncthreads();
+      for (int pos = 0; pos < LL; ++pos) {
+        const int ts = s_ts[pos];
+        int td = s_td[pos];
         if (ts < 0 && td < 0) continue;
         if (ts >= 0) {
             int sb[4], db[4] = {INT_MAX, -1, INT_MAX, -1};
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
                 a.pending_free[atomicAdd(a.n_pending, 1)] = td;   // pushed back after the kernel
             }
         }
+      }
     }
 }
 

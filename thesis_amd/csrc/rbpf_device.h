@@ -21,6 +21,28 @@ __device__ __forceinline__ bool lookup_cell(const DevView& v, const int32_t* __r
     return true;
 }
 
+// Same result as lookup_cell with one multiply-add per axis instead of four float64 divisions: the quotients are
+// evaluated approximately and the reference's exact expressions (gridmap.py:126, hybridmap.py:44-45) are used only
+// when an approximate value lies within 1e-6 of an integer, i.e. when the two could truncate differently.
+__device__ __forceinline__ bool lookup_cell_fast(const DevView& v, const int32_t* __restrict__ tab,
+                                                 double gx, double gy, int& val) {
+    const double half = v.tile_len * 0.5, inv_len = 1.0 / v.tile_len, scale = (double)v.dim * inv_len, hd = (double)v.dim * 0.5;
+    const double tx = (gx + half) * inv_len, ty = (gy + half) * inv_len;
+    const double fxl = __builtin_floor(tx), fyl = __builtin_floor(ty);
+    const double qx = (gx - fxl * v.tile_len) * scale + hd, qy = (gy - fyl * v.tile_len) * scale + hd;   // in [0, dim)
+    const double rx = qx - __builtin_floor(qx), ry = qy - __builtin_floor(qy);
+    const double ux = tx - fxl, uy = ty - fyl;
+    const double eps = 1e-6;
+    if (!(rx > eps && rx < 1 - eps && ry > eps && ry < 1 - eps && ux > eps && ux < 1 - eps && uy > eps && uy < 1 - eps))
+        return lookup_cell(v, tab, gx, gy, val);
+    const int lx = (int)fxl, ly = (int)fyl;
+    if (lx < -v.R || lx > v.R || ly < -v.R || ly > v.R) return false;
+    const int t = tab[(lx + v.R) * v.L + (ly + v.R)];
+    if (t < 0) return false;
+    val = v.pool[(size_t)t * v.dim * v.dim + (size_t)(int)qx * v.dim + (int)qy];
+    return true;
+}
+
 // ---- LUT helpers ------------------------------------------------------------------------------
 __device__ __forceinline__ bool lut_valid_g(const DevView& v, int g) {
     return g >= v.g_min && g < v.g_min + v.n_lut;
