@@ -533,8 +533,34 @@ int rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const
     *score_out = valid ? out[12] : 0.0;
     return RBPF_OK;
 }
-int rbpf_match_inputs(rbpf_handle* h, int32_t, const double*, double*, int32_t*, double*, int32_t*, int32_t) {
-    return fail(h, RBPF_ESTATE, "rbpf_match_inputs: not built yet");
+// HybridMap.get_scan_match up to the engine call (hybridmap.py:210-242) for one particle: the curr / ref point lists
+int rbpf_match_inputs(rbpf_handle* h, int32_t particle, const double* guess3, double* curr_xy, int32_t* n_curr,
+                      double* ref_xy, int32_t* n_ref, int32_t cap_ref) {
+    if (!h || !guess3 || !curr_xy || !n_curr || !ref_xy || !n_ref || cap_ref < 0) return RBPF_EINVAL;
+    if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
+    DevView& v = h->v;
+    if (particle < 0 || particle >= v.P) return fail(h, RBPF_EINVAL, "particle index out of range");
+    const size_t LL = (size_t)v.L * v.L, mask_words = LL * v.dim * v.ow, n_rows = (size_t)v.L * v.dim;
+    double *d_all = nullptr, *d_ref = nullptr, *d_curr = nullptr; int* d_counts = nullptr; uint32_t* d_mask = nullptr; int* d_rows = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_all, (size_t)v.B * 16)); HIP_TRY(h, hipMalloc((void**)&d_curr, (size_t)v.B * 16));
+    HIP_TRY(h, hipMalloc((void**)&d_ref, std::max<size_t>(cap_ref, 1) * 16)); HIP_TRY(h, hipMalloc((void**)&d_counts, 16));
+    HIP_TRY(h, hipMalloc((void**)&d_mask, mask_words * 4)); HIP_TRY(h, hipMalloc((void**)&d_rows, n_rows * 4));
+    HIP_TRY(h, hipMemsetAsync(d_mask, 0, mask_words * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(d_counts, 0, 16, h->stream));
+    const int win = (int)(1.8 / h->cfg.cell_size);                 // gridmap.py:143
+    launch_match_inputs(v, particle, guess3, d_all, d_counts, d_mask, d_rows, d_ref, cap_ref, d_curr, win,
+                        h->cfg.match_max_range, h->stream);
+    int counts[3] = {0, 0, 0};
+    HIP_TRY(h, hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, h->stream));
+    int rc = check_device_error(h);
+    if (rc == RBPF_OK) {
+        *n_curr = counts[1]; *n_ref = counts[2];
+        if (counts[1] > 0) HIP_TRY(h, hipMemcpy(curr_xy, d_curr, (size_t)counts[1] * 16, hipMemcpyDeviceToHost));
+        int nr = std::min(counts[2], cap_ref);
+        if (nr > 0) HIP_TRY(h, hipMemcpy(ref_xy, d_ref, (size_t)nr * 16, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_all); (void)hipFree(d_curr); (void)hipFree(d_ref); (void)hipFree(d_counts); (void)hipFree(d_mask); (void)hipFree(d_rows);
+    return rc;
 }
 
 // ---- resample (main.py:46-79) -------------------------------------------------------------------------------

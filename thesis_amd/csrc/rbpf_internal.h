@@ -135,5 +135,8 @@ void launch_match_particles(const DevView& v, int mode, const double* d_ref, int
 void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
                          const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
                          double d0, int ncr, int cap_sel, size_t lds, hipStream_t s);
+void launch_match_inputs(const DevView& v, int particle, const double* guess3, double* d_all_curr, int* d_counts,
+                         uint32_t* d_mask, int* d_row_cnt, double* d_ref, int cap_ref, double* d_curr, int win,
+                         double match_max, hipStream_t s);
 size_t raycast_lds_bytes(int B);
 }  // namespace rbpf

@@ -152,6 +152,14 @@ class ParticleEngine:
             self._h, int(adj), None if ls is None else _dp(ls), 0 if ls is None else len(ls),
             None if mo is None else _dp(mo), None if gs is None else _dp(gs)))
 
+    def match_inputs(self, particle: int, guess, cap_ref: int = 1 << 16):
+        """The (curr, ref) point lists HybridMap.get_scan_match would hand to the matcher (hybridmap.py:210-242)."""
+        g = _f64(guess).reshape(3)
+        curr = np.empty((max(self.n_beams, 1), 2)); ref = np.empty((cap_ref, 2))
+        nc, nr = C.c_int32(), C.c_int32()
+        self._check(self._lib.rbpf_match_inputs(self._h, particle, _dp(g), _dp(curr), C.byref(nc), _dp(ref), C.byref(nr), cap_ref))
+        return curr[:nc.value].copy(), ref[:min(nr.value, cap_ref)].copy()
+
     def resample(self, u: float = float("nan")) -> Tuple[bool, np.ndarray]:
         idx = np.empty(self.P, dtype=np.int32)
         did = C.c_int32()
