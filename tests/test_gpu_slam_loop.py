@@ -1,0 +1,48 @@
+"""The reference's main loop (main.py:138-214) over the engine: BASELINE config C1 (Intel log, 64 particles,
+0.1 m grid, native 180 beams) on the first scans of data/intel.txt (a data fixture, tests/golden/intel_head.log)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_intel_replay_c1():
+    from thesis_amd.datasets.carmen import load_carmen
+    from thesis_amd.slam import ParticleFilter, run_log
+    log = load_carmen(os.path.join(HERE, "golden", "intel_head.log"))
+    assert log.scans.shape[1] == 180 and len(log.scans) >= 70
+    pf = ParticleFilter(64, log.angles, motion_model="absolute", cell_size=0.1)
+    res = run_log(pf, log.scans, log.scan_times, log.odom, log.odom_times, max_frames=70, order=log.order)
+    assert res.frames == 70 and res.accepted >= 8
+    poses = pf.engine.poses()
+    assert np.all(np.isfinite(poses)) and np.all(np.isfinite(pf.engine.weights()))
+    # particles stay near the odometry track (the absolute model passes ODOM poses through, IntelIMUData.py:23-25)
+    pos = int(np.nonzero(log.order == 69)[0][0])               # record of the 70th scan in the file
+    last_odom = -int(log.order[:pos][log.order[:pos] < 0][-1]) - 1
+    assert np.all(np.linalg.norm(poses[:, :2] - log.odom[last_odom, :2], axis=1) < 1.5)
+    xs, ys = pf.particles[0]._map.get_occupied_points()
+    assert len(xs) > 300                                   # walls have been mapped
+    traj = pf.trajectory(0)
+    assert len(traj) > 70 and np.all(np.isfinite(np.array(traj)))
+    assert pf.particles[0]._map.get_odds_at((0.0, 0.0)) is not None
+    pf.close()
+
+
+def test_synthetic_room_loop_tracks_truth():
+    """Velocity-model odometry with 1 % noise + built-in matcher: particle 0 stays within 0.15 m of the truth."""
+    from thesis_amd.datasets import synthetic
+    from thesis_amd.slam import ParticleFilter, run_log
+    period = 0.7
+    angles, ranges, odo, truth = synthetic.make_log(40, 361, period=period)
+    scan_times = (np.arange(41) * period * 1e4).astype(np.int64)
+    odom_times = scan_times[1:] - 1                       # the reading that moves k -> k+1 arrives just before scan k+1
+    pf = ParticleFilter(128, angles, motion_model="velocity", cell_size=0.05)
+    # readings carry dt = time since the previous reading
+    res = run_log(pf, ranges, scan_times, odo, odom_times)
+    assert res.accepted >= 30
+    p0 = np.array(pf.particles[0].get_latest_pose())
+    assert np.linalg.norm(p0[:2] - truth[-1, :2]) < 0.15 and abs(p0[2] - truth[-1, 2]) < 0.05
+    pf.close()
