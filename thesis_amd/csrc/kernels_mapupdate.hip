@@ -42,21 +42,25 @@ namespace rbpf {
 // thread of the workgroup wrote in the same kernel, so the HBM read-modify-writes may stay in flight across it.
 #define BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// a value every lane agrees on, moved to a scalar register (values read from LDS are not known to be uniform)
+#define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+
 static const int MU_BLOCK = 512;       // 8 waves per particle
 static const int NB_MAX = 1536;        // bucket ids per window (flagged cells beyond it take the membership-scan path)
-static const int EV_TOT = 5120;        // event slots per window
+static const int EV_TOT = 4096;        // event slots per window
 static const int CHUNK = 16;           // ray steps per work item of the walk
 
+__host__ __device__ inline int mu_fan_width(int reach) { return (2 * reach + 8 + 7) & ~7; }
 __host__ __device__ inline int mu_nb(int B) { int nb = 2 * B; return nb < NB_MAX ? nb : NB_MAX; }
 // chunk table entries: every ray has at most ceil((WIN + 2) / CHUNK) = 9 chunks in a window; the same memory later
 // holds the two replay work lists (NB deep buckets + the overflow list)
 __host__ __device__ inline int mu_chunk_cap(int B) { int a = 9 * B, b = 2 * mu_nb(B) + 64; int c = a > b ? a : b; return (c + 7) & ~7; }
 
-size_t raycast_lds_bytes(int B) {
+size_t raycast_lds_bytes(int B, int reach) {
     size_t nb = mu_nb(B);
     size_t bpad = (size_t)((B + 3) & ~3);
     size_t bytes = (size_t)WIN * WIN / 2 * 4 + (size_t)WIN * WIN / 32 * 4 + (size_t)WIN * WIN / 32 * 2 + (size_t)EV_TOT * 2 + nb * 2 +
-                   (size_t)mu_chunk_cap(B) * 2 + 2 * (WIN + 8) * 2 + bpad * 4 + bpad * 2 * 2 + 256 + (size_t)((B + 15) & ~15) + ((nb + 15) & ~(size_t)15);
+                   (size_t)mu_chunk_cap(B) * 2 + 2 * (size_t)mu_fan_width(reach) * 2 + bpad * 4 + bpad * 2 * 2 + 256 + (size_t)((B + 15) & ~15) + ((nb + 15) & ~(size_t)15);
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -71,8 +75,8 @@ struct MuLds {
     uint16_t* bcell;  // [NB] local cell index of bucket id
     uint8_t*  oldv;   // [NB] value of the flagged cell before this scan (from the prefetched words)
     uint16_t* chunk;  // [CH_CAP] walk work items (beam << 3) | chunk; later the replay work lists
-    int16_t*  lutx;   // [WIN+8]
-    int16_t*  luty;
+    uint16_t* fanx;   // [FANW] storage cell index of every global column the ray fan can reach (x axis)
+    uint16_t* fany;   // [FANW] same for y; both filled once per particle from the global-index LUT
     int32_t*  r_end;  // [B] packed (dx & 0xFFFF) | (dy << 16) relative to the start cell
     int16_t*  seg_lo; // [B] first / last step of the ray inside the current window
     int16_t*  seg_hi;
@@ -123,6 +127,14 @@ __device__ __forceinline__ Caf caf_then(Caf f, Caf g) {          // g after f
     return r;
 }
 __device__ __forceinline__ int caf_apply(Caf f, int x) { int t = x + f.a; t = t < f.lo ? f.lo : t; return t > f.hi ? f.hi : t; }
+
+// first global index g in [lo, hi] whose storage index fan[g - f0] is >= target (hi + 1 if none), from a close guess
+__device__ __forceinline__ int fan_first_ge(const uint16_t* fan, int f0, int lo, int hi, int target, int guess) {
+    int g = min(max(guess, lo), hi + 1);
+    while (g > lo && (int)fan[g - 1 - f0] >= target) --g;
+    while (g <= hi && (int)fan[g - f0] < target) ++g;
+    return g;
+}
 
 // a hit on a flagged cell: the counter value returned by the atomic is the event's slot in the cell's bucket
 __device__ __forceinline__ void walk_flagged(const MuLds& s, int cc, uint32_t hv, int b, int rem, bool occ, bool near_ok,
@@ -227,9 +239,10 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     s.bev = s.fpre + WIN * WIN / 32;
     s.bcell = s.bev + EV_TOT;
     s.chunk = s.bcell + NB;
-    s.lutx = reinterpret_cast<int16_t*>(s.chunk + CH_CAP);
-    s.luty = s.lutx + (WIN + 8);
-    s.r_end = reinterpret_cast<int32_t*>(s.luty + (WIN + 8));
+    const int FANW = mu_fan_width(v.reach);
+    s.fanx = s.chunk + CH_CAP;
+    s.fany = s.fanx + FANW;
+    s.r_end = reinterpret_cast<int32_t*>(s.fany + FANW);
     s.seg_lo = reinterpret_cast<int16_t*>(s.r_end + BPAD);
     s.seg_hi = s.seg_lo + BPAD;
     s.dummy = reinterpret_cast<uint32_t*>(s.seg_hi + BPAD);
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     __shared__ int s_x0, s_y0, s_skip;
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];                       // ray fan bounding box: gx min, gx max, gy min, gy max
-    __shared__ int s_nflag, s_bb[4], s_written, s_nslow, s_nbig, s_nchunk, s_ident, s_wsum[MU_BLOCK / 64], s_tot_written, s_tot_slow;
+    __shared__ int s_nflag, s_bb[4], s_written, s_nslow, s_nbig, s_nchunk, s_irreg, s_wsum[MU_BLOCK / 64], s_tot_written, s_tot_slow;
     static_assert(WIN * WIN / 32 == MU_BLOCK, "one flag word per thread");
     __shared__ unsigned long long s_cells;
 
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     __syncthreads();
     if (s_skip) return;
 
-    const int x0 = s_x0, y0 = s_y0;
+    const int x0 = UNI(s_x0), y0 = UNI(s_y0);
     const int a0 = lut_lat(lut_at(v, x0)), b0 = lut_lat(lut_at(v, y0));
     {
         unsigned long long my_cells = 0;
@@ -342,6 +355,13 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
         }
     }
     __syncthreads();
+    // the storage index of every global column of the fan, once per particle (the window loop never reads the LUT again)
+    const int fx0 = UNI(s_fan[0] - 1), fy0g = UNI(s_fan[2] - 1);
+    for (int i = tid; i < FANW; i += MU_BLOCK) {
+        const int gxq = fx0 + i, gyq = fy0g + i;
+        s.fanx[i] = lut_valid_g(v, gxq) ? (uint16_t)lut_cidx(lut_at(v, gxq)) : 0xFFFFu;
+        s.fany[i] = lut_valid_g(v, gyq) ? (uint16_t)lut_cidx(lut_at(v, gyq)) : 0xFFFFu;
+    }
     // allocate missing tiles (free tiles are kept zero-filled)
     if (tid < LL && s_need[tid] && s_tab[tid] < 0) {
         int idx = atomicSub(v.free_top, 1) - 1;
@@ -367,60 +387,48 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
     for (int t = 0; t < LL; ++t) {
         if (!s_need[t]) continue;                          // uniform over the workgroup
         const int la = t / v.L, lb = t % v.L;
-        const int tile = s_tab[t];
+        const int tile = UNI(s_tab[t]);
         const int* gwx = v.gwin + la * (KW + 1);
         const int* gwy = v.gwin + lb * (KW + 1);
-        const int lox = max(gwx[0], s_fan[0]), hix = min(gwx[KW] - 1, s_fan[1]);
-        const int loy = max(gwy[0], s_fan[2]), hiy = min(gwy[KW] - 1, s_fan[3]);
+        const int lox = UNI(max(gwx[0], s_fan[0])), hix = UNI(min(gwx[KW] - 1, s_fan[1]));
+        const int loy = UNI(max(gwy[0], s_fan[2])), hiy = UNI(min(gwy[KW] - 1, s_fan[3]));
         if (lox > hix || loy > hiy) continue;
-        const int wx_lo = lut_cidx(lut_at(v, lox)) / WIN, wx_hi = lut_cidx(lut_at(v, hix)) / WIN;
-        const int wy_lo = lut_cidx(lut_at(v, loy)) / WIN, wy_hi = lut_cidx(lut_at(v, hiy)) / WIN;
+        // windows are placed relative to the fan: x from the first touched storage column, y from the first touched
+        // 32-cell group (the write-back and the occupancy words are 32 cells wide)
+        const int cx_lo = UNI(s.fanx[lox - fx0]), cx_hi = UNI(s.fanx[hix - fx0]);
+        const int cy_lo = UNI(s.fany[loy - fy0g] & ~31), cy_hi = UNI(s.fany[hiy - fy0g]);
         int8_t* __restrict__ tile_base = v.pool + (size_t)tile * tile_cells;
         int tile_bb[4] = {INT_MAX, -1, INT_MAX, -1};       // thread 0 accumulates the tile's written box
 
-        for (int wxi = wx_lo; wxi <= wx_hi; ++wxi)
-        for (int wyi = wy_lo; wyi <= wy_hi; ++wyi) {
-            const int wx0 = wxi * WIN, wy0 = wyi * WIN;
-            const int gxa = gwx[wxi], gxb = gwx[wxi + 1], gya = gwy[wyi], gyb = gwy[wyi + 1];   // [gxa,gxb) x [gya,gyb)
+        for (int wx0 = cx_lo; wx0 <= cx_hi; wx0 += WIN)
+        for (int wy0 = cy_lo; wy0 <= cy_hi; wy0 += WIN) {
+            // global index range [gxa,gxb) x [gya,gyb) of the window: the storage index is non-decreasing in the global one
+            // (the index map is the identity plus an offset up to isolated off-by-one glitches: start from that guess)
+            const int gxa = UNI(fan_first_ge(s.fanx, fx0, lox, hix, wx0, lox + (wx0 - cx_lo)));
+            const int gxb = UNI(fan_first_ge(s.fanx, fx0, lox, hix, wx0 + WIN, lox + (wx0 + WIN - cx_lo)));
+            const int gya = UNI(fan_first_ge(s.fany, fy0g, loy, hiy, wy0, loy + (wy0 - (int)s.fany[loy - fy0g])));
+            const int gyb = UNI(fan_first_ge(s.fany, fy0g, loy, hiy, wy0 + WIN, loy + (wy0 + WIN - (int)s.fany[loy - fy0g])));
+            if (gxa >= gxb || gya >= gyb) continue;        // uniform
             const int nx_ = gxb - gxa, ny_ = gyb - gya;
-            if (tid == 0) s_ident = 1;
+            const uint16_t* lutx = s.fanx + (gxa - fx0);   // storage column of global column gxa + i: lutx[i] - wx0 is window-local
+            const uint16_t* luty = s.fany + (gya - fy0g);
+            const int offx = UNI((int)lutx[0] - wx0), offy = UNI((int)luty[0] - wy0);
+            if (tid == 0) s_irreg = 0;
             BAR_LDS();                                     // previous window fully done with LDS
-            // ---- phase 0: clear the counters, local index maps ----------------------------------------------------
+            // ---- phase 0: clear the counters; is the window's index map a pure offset?  (No off-by-one glitch of the
+            //      reference's index formula inside: always the case on the positive side of a tile, SURVEY quirk 3.
+            //      A repeat and a skip can cancel, so every step is checked.)
+            for (int i = tid; i < nx_ - 1; i += MU_BLOCK) if ((int)lutx[i + 1] - (int)lutx[i] != 1) s_irreg = 1;
+            for (int i = tid; i < ny_ - 1; i += MU_BLOCK) if ((int)luty[i + 1] - (int)luty[i] != 1) s_irreg = 1;
+            // ---- clear the counters ----------------------------------------------------
             {
                 uint4* c4 = reinterpret_cast<uint4*>(s.cnt);
                 for (int i = tid; i < WIN * WIN / 8; i += MU_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
                 for (int i = tid; i < WIN * WIN / 32; i += MU_BLOCK) s.flag[i] = 0;
-                // local index maps; `s_ident` stays 1 when both are pure offsets (no off-by-one glitch of the reference's
-                // index formula inside this window: always the case on the positive side of a tile)
-                for (int i = tid; i < nx_ && i < WIN + 8; i += MU_BLOCK) {
-                    const int val = lut_cidx(lut_at(v, gxa + i)) - wx0;
-                    s.lutx[i] = (int16_t)val;
-                    if (val != lut_cidx(lut_at(v, gxa)) - wx0 + i) s_ident = 0;
-                }
-                for (int i = tid; i < ny_ && i < WIN + 8; i += MU_BLOCK) {
-                    const int val = lut_cidx(lut_at(v, gya + i)) - wy0;
-                    s.luty[i] = (int16_t)val;
-                    if (val != lut_cidx(lut_at(v, gya)) - wy0 + i) s_ident = 0;
-                }
                 if (tid == 0) {
                     s_nflag = 0; s_written = 0; s_nslow = 0; s_nbig = 0; s_nchunk = 0;
                     s_bb[0] = INT_MAX; s_bb[1] = -1; s_bb[2] = INT_MAX; s_bb[3] = -1;
                 }
-            }
-            // prefetch this thread's 32-cell group of the window (128 rows x 4 groups = 512 threads): the HBM read latency
-            // overlaps the LDS phases, the read-modify-write at the end only stores
-            const int g_lx = tid / (WIN / 32), g_ly = (tid % (WIN / 32)) * 32;
-            const int g_row = wx0 + g_lx, g_col = wy0 + g_ly;
-            const bool g_in = g_row < v.dim && g_col < v.dim;
-            const int g_nw = g_in ? min(8, (v.dim - g_col) >> 2) : 0;    // words inside the row (dim is a multiple of 16)
-            uint32_t* const g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)(g_in ? g_row : 0) * v.dim + (g_in ? g_col : 0));
-            uint32_t pre[8];
-            if (g_nw == 8) {
-                const uint4 a0 = reinterpret_cast<const uint4*>(g_ptr)[0], a1 = reinterpret_cast<const uint4*>(g_ptr)[1];
-                pre[0] = a0.x; pre[1] = a0.y; pre[2] = a0.z; pre[3] = a0.w; pre[4] = a1.x; pre[5] = a1.y; pre[6] = a1.z; pre[7] = a1.w;
-            } else {
-#pragma unroll
-                for (int w = 0; w < 8; ++w) pre[w] = w < g_nw ? g_ptr[w] : 0u;
             }
             BAR_LDS();
             STAMP(1);
@@ -435,14 +443,14 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     unpack_end(s.r_end[b], x0, y0, x1, y1);
                     if ((info & RI_OCC)) {                                              // hybridmap.py:113,137
                         if (x1 >= gxa && x1 < gxb && y1 >= gya && y1 < gyb) {
-                            int c = s.lutx[x1 - gxa] * WIN + s.luty[y1 - gya];
+                            int c = ((int)lutx[x1 - gxa] - wx0) * WIN + ((int)luty[y1 - gya] - wy0);
                             atomicOr(&s.flag[c >> 5], 1u << (c & 31));
                             atomicOr(&s.cnt[c >> 1], 0x8000u << ((c & 1) * 16));
                         }
                         if (info & RI_NEAR) {                                         // hybridmap.py:139-142
                             int nx = x1 + ((info >> 3) & 3) - 1, ny = y1 + ((info >> 5) & 3) - 1;
                             if (nx >= gxa && nx < gxb && ny >= gya && ny < gyb) {
-                                int c = s.lutx[nx - gxa] * WIN + s.luty[ny - gya];
+                                int c = ((int)lutx[nx - gxa] - wx0) * WIN + ((int)luty[ny - gya] - wy0);
                                 atomicOr(&s.flag[c >> 5], 1u << (c & 31));
                                 atomicOr(&s.cnt[c >> 1], 0x8000u << ((c & 1) * 16));
                             }
@@ -499,28 +507,21 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                 uint32_t bb = bits; int id = excl;
                 while (bb) {                                  // flag word w covers exactly this thread's prefetched group
                     int bit = __ffs(bb) - 1; bb &= bb - 1;
-                    if (id < NB) {
-                        s.bcell[id] = (uint16_t)(w * 32 + bit);
-                        uint32_t wsel = pre[0];
-#pragma unroll
-                        for (int q = 1; q < 8; ++q) wsel = (bit >> 2) == q ? pre[q] : wsel;
-                        s.oldv[id] = (uint8_t)((wsel >> (8 * (bit & 3))) & 0xFFu);
-                    }
+                    if (id < NB) s.bcell[id] = (uint16_t)(w * 32 + bit);
                     ++id;
                 }
             }
             BAR_LDS();
             // event slots are shared out evenly: few flagged cells (a near wall under dense beams) get deep buckets
-            const int nflag = s_nflag;
+            const int nflag = UNI(s_nflag);
             const int cap = min(64, max(4, EV_TOT / max(nflag, 1)));
             const int nbk = min(min(nflag, NB), EV_TOT / cap);
             STAMP(2);
 
             // ---- phase 2: walk the clipped rays, CHUNK steps per work item, four steps in flight ------------------------
             {
-                const int nchunk = min(s_nchunk, CH_CAP);
-                const bool ident = s_ident != 0;
-                const int offx = s.lutx[0], offy = s.luty[0];             // local index of the window's first global column
+                const int nchunk = UNI(min(s_nchunk, CH_CAP));
+                const bool ident = UNI(s_irreg) == 0;
                 if (s_nchunk > CH_CAP && tid == 0) atomicCAS(v.err, 0, RBPF_ENOMEM);   // cannot happen: B*5 entries
                 for (int q = tid; q < nchunk; q += MU_BLOCK) {
                     const int desc = s.chunk[q];
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                             int ix = (r.steep ? mnr : maj) - gxa, iy = (r.steep ? maj : mnr) - gya;
                             if (live) { if (D >= 0) { ++m; D -= 2 * r.dmaj; } D += 2 * r.dmin; }
                             ix = min(max(ix, 0), nx_ - 1); iy = min(max(iy, 0), ny_ - 1);
-                            lxv[u] = s.lutx[ix]; lyv[u] = s.luty[iy];
+                            lxv[u] = (int)lutx[ix] - wx0; lyv[u] = (int)luty[iy] - wy0;
                             c[u] = live ? 0 : -1;
                         }
 #pragma unroll
@@ -641,6 +642,35 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
             }
             BAR_LDS();
             STAMP(3);
+            // prefetch this thread's 32-cell group of the window (128 rows x 4 groups = 512 threads): issued
+            // after the walk (holding eight more registers across it makes the compiler spill them to scratch)
+            const int g_lx = tid / (WIN / 32), g_ly = (tid % (WIN / 32)) * 32;
+            const int g_row = wx0 + g_lx, g_col = wy0 + g_ly;
+            const bool g_in = g_row < v.dim && g_col < v.dim;
+            const int g_nw = g_in ? min(8, (v.dim - g_col) >> 2) : 0;    // words inside the row (dim is a multiple of 16)
+            uint32_t* const g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)(g_in ? g_row : 0) * v.dim + (g_in ? g_col : 0));
+            uint32_t pre[8];
+            if (g_nw == 8) {
+                const uint4 a0 = reinterpret_cast<const uint4*>(g_ptr)[0], a1 = reinterpret_cast<const uint4*>(g_ptr)[1];
+                pre[0] = a0.x; pre[1] = a0.y; pre[2] = a0.z; pre[3] = a0.w; pre[4] = a1.x; pre[5] = a1.y; pre[6] = a1.z; pre[7] = a1.w;
+            } else {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) pre[w] = w < g_nw ? g_ptr[w] : 0u;
+            }
+            {   // values of this group's flagged cells before the scan, for the replay (flag word `tid` = this group)
+                uint32_t bb = s.flag[tid]; int id = s.fpre[tid];
+                while (bb) {
+                    const int bit = __ffs(bb) - 1; bb &= bb - 1;
+                    if (id < NB) {
+                        uint32_t wsel = pre[0];
+#pragma unroll
+                        for (int q = 1; q < 8; ++q) wsel = (bit >> 2) == q ? pre[q] : wsel;
+                        s.oldv[id] = (uint8_t)((wsel >> (8 * (bit & 3))) & 0xFFu);
+                    }
+                    ++id;
+                }
+            }
+            BAR_LDS();
 
             // ---- phase 3: flagged cells, ordered replay; the new value goes back into the cell's LDS slot ----------------
             // (the chunk table is dead now: its memory holds the two work lists of this phase)
@@ -707,8 +737,8 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     const int c = slowc[k];
                     const int lx = c / WIN, ly = c % WIN;
                     int gxc[4], gyc[4], ngx = 0, ngy = 0;
-                    for (int i = 0; i < nx_ && ngx < 4; ++i) if (s.lutx[i] == lx) gxc[ngx++] = gxa + i;
-                    for (int i = 0; i < ny_ && ngy < 4; ++i) if (s.luty[i] == ly) gyc[ngy++] = gya + i;
+                    for (int i = 0; i < nx_ && ngx < 4; ++i) if ((int)lutx[i] - wx0 == lx) gxc[ngx++] = gxa + i;
+                    for (int i = 0; i < ny_ && ngy < 4; ++i) if ((int)luty[i] - wy0 == ly) gyc[ngy++] = gya + i;
                     int val = replay_cell_wave(v, s, x0, y0, gxc, ngx, gyc, ngy,
                                                (int)tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)], lane);
                     if (lane == 0) cnt16_set(s.cnt, c, 0x8000u | ((uint32_t)val & 0xFFu));
@@ -802,7 +832,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
 }
 
 void launch_map_update_fused(const DevView& v, hipStream_t s) {
-    size_t lds = raycast_lds_bytes(v.B);
+    size_t lds = raycast_lds_bytes(v.B, v.reach);
     static size_t lds_attr = 0;
     if (lds > lds_attr) {   // more than the default 64 KiB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(map_update_kernel),

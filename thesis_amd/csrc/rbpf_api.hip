@@ -209,7 +209,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.msel_x, (size_t)c.max_beams); ALLOC(h, v.msel_y, (size_t)c.max_beams);
         ALLOC(h, v.asel_x, (size_t)c.max_beams); ALLOC(h, v.asel_y, (size_t)c.max_beams);
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
-        if (raycast_lds_bytes(c.max_beams) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
+        if (raycast_lds_bytes(c.max_beams, v.reach) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
         match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
         h->mlds = match_lds_bytes(h->mN, c.max_beams, match_max_coarse(h->mncr, 0.7, h->mmcs));
         if (h->mlds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this cell_size");

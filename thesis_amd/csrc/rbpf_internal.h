@@ -138,5 +138,5 @@ void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const
 void launch_match_inputs(const DevView& v, int particle, const double* guess3, double* d_all_curr, int* d_counts,
                          uint32_t* d_mask, int* d_row_cnt, double* d_ref, int cap_ref, double* d_curr, int win,
                          double match_max, hipStream_t s);
-size_t raycast_lds_bytes(int B);
+size_t raycast_lds_bytes(int B, int reach);
 }  // namespace rbpf
