@@ -644,7 +644,8 @@ int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int3
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
     HIP_TRY(h, hipMemcpyAsync(v.global_id, new_global_id, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
-    return check_device_error(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));        // the host arrays may be reused by the caller; errors surface at the next check
+    return RBPF_OK;
 }
 
 int32_t rbpf_pack_meta_width(rbpf_handle* h) { return h ? 2 + 6 * h->v.L * h->v.L : -1; }

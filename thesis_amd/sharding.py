@@ -206,6 +206,13 @@ class ShardedResampler:
             return False, None
         plan = plan_migration(idx, self.owner, self.local_of, self.world, self.p_local)
         r, W = self.rank, sh.meta_width
+        if plan.n_move == 0:                                                 # every rank sees the same plan: no exchange
+            sh.apply_local(plan.new_src[r], plan.new_gid[r])
+            for q in range(self.world):
+                self.owner[plan.new_gid[q]] = q
+                self.local_of[plan.new_gid[q]] = np.arange(len(plan.new_gid[q]), dtype=np.int32)
+            self.stats["resamples"] += 1
+            return True, idx
         # pack what leaves this rank, destination by destination
         metas, payloads, n_out, b_out = [], [], [], []
         for d in range(self.world):
