@@ -354,3 +354,39 @@ def test_match_inputs_golden(golden, eng_mod, case):
     order = [tuple(p) for p in ref]
     assert order == sorted(order)                                       # np.unique order: by x, then y
     e.close()
+
+
+def test_full_size_step_properties_c3(eng_mod):
+    """BASELINE config 3 size (4096 particles, 1081 beams, 0.05 m): one full step + resample, size-independent
+    properties: finite state, lattice range, non-decreasing ancestors covering [0, P), tile accounting, and the
+    per-particle ray-cell / written-cell counters equal to the oracle's for a particle at the same pose."""
+    from thesis_amd.datasets import synthetic
+    P, B = 4096, 1081
+    ang = synthetic.beam_angles(B)
+    rng = np.random.Generator(np.random.PCG64(2))
+    r0 = synthetic.cast_scan((0.0, 0.0, 0.0), ang, rng)
+    e = eng_mod.ParticleEngine(P, max_beams=B, pool_tiles=2 * P)
+    e.set_scan(r0, ang)
+    e.map_update(np.zeros((P, 3)))
+    c = e.counters()
+    hm = orc.OracleHybridMap(0.05)
+    sx, sy = orc.scan_xy(r0, ang)
+    hm.update((0.0, 0.0, 0.0), sx, sy)
+    assert c["ray_cells_visited"] == P * hm.cells_visited
+    assert c["cells_written"] == P * int(np.count_nonzero(hm.tiles[0].map))
+    e.imu_update("velocity", [0.5, 0.0, 0.1], 7000.0)
+    r1 = synthetic.cast_scan((0.35, 0.0, 0.07), ang, rng)
+    e.set_scan(r1, ang)
+    e.scan_update(adj=False)
+    did, idx = e.resample(0.4242)
+    poses, w = e.poses(), e.weights()
+    assert np.all(np.isfinite(poses)) and np.all(np.isfinite(e.covs()))
+    assert np.all(np.abs(poses - [0.35, 0.0, 0.07]) < [0.2, 0.2, 0.05])
+    assert np.all(np.diff(idx) >= 0) and idx[0] >= 0 and idx[-1] < P
+    if did:
+        assert np.all(w == 1.0)
+    assert e.counters()["tiles_in_use"] == P
+    for p in (0, P // 2, P - 1):
+        (centre, cells), = e.tiles(p)
+        assert centre == (0.0, 0.0) and cells.min() >= -30 and cells.max() <= 30 and np.count_nonzero(cells) > 40000
+    e.close()
