@@ -92,6 +92,7 @@ typedef struct rbpf_counters {
     double   ms_resample;         /* ... of the last resample (plan + copies)                     */
     uint64_t slow_cells;          /* flagged cells that overflowed their ordered-event bucket     */
     uint64_t reserved[7];
+    uint64_t window_fallbacks;    /* particles the whole-fan map update handed to the 128x128-window kernel */
 } rbpf_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

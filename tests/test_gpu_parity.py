@@ -17,6 +17,17 @@ def eng_mod():
     return engine
 
 
+@pytest.fixture(params=["fan", "window"])
+def map_kernel(request, monkeypatch):
+    """Both map-update kernels: the whole-fan kernel (default where its LDS layout fits) and the 128x128-window
+    kernel (RBPF_MAP_KERNEL=window, read by rbpf_create)."""
+    if request.param == "window":
+        monkeypatch.setenv("RBPF_MAP_KERNEL", "window")
+    else:
+        monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
+    return request.param
+
+
 def to_lattice(vals):
     """float64 log-odds of the reference -> int8 lattice value; asserts the lattice claim."""
     q = np.rint(np.asarray(vals) / Q)
@@ -83,7 +94,7 @@ def test_weight_samples_golden(golden, eng_mod, case):
 
 
 @pytest.mark.parametrize("case", list("abcdefg"))
-def test_map_update_golden(golden, eng_mod, case):
+def test_map_update_golden(golden, eng_mod, case, map_kernel):
     g = golden("G3_map_update")
     cs = float(g[case + "_cs"])
     P = 2
@@ -96,7 +107,7 @@ def test_map_update_golden(golden, eng_mod, case):
     e.close()
 
 
-def test_map_update_random_particles_vs_oracle(eng_mod):
+def test_map_update_random_particles_vs_oracle(eng_mod, map_kernel):
     """Distinct poses per particle, three scans, compared cell by cell with the oracle."""
     from thesis_amd.datasets import synthetic
     rng = np.random.Generator(np.random.PCG64(321))
@@ -121,10 +132,59 @@ def test_map_update_random_particles_vs_oracle(eng_mod):
         assert_tiles_equal(e, p, oracle_dump(maps[p]), e.dim)
     c = e.counters()
     assert c["ray_cells_visited"] > 0 and c["cells_written"] > 0
+    if map_kernel == "window":
+        assert c["window_fallbacks"] == 0
     e.close()
 
 
-def test_map_update_ray_cell_count_matches_oracle(eng_mod):
+@pytest.mark.parametrize("scene", ["near_wall", "one_direction", "tile_corner", "negative_side", "short_rays"])
+def test_map_update_fan_kernel_hard_cases(eng_mod, scene):
+    """Inputs chosen against the whole-fan kernel's layout limits: cells hit by more rays than an 8-bit field may
+    hold (the particle is handed to the window kernel), fans that straddle four tiles, the irregular stretch of
+    the reference's index formula on the negative side, many flagged cells.  Cell-exact against the oracle."""
+    from thesis_amd.datasets import synthetic
+    rng = np.random.Generator(np.random.PCG64(77))
+    B = 1081
+    ang = synthetic.beam_angles(B)
+    if scene == "near_wall":            # 0.3 m in front of a wall: the wall cells collect dozens of hits each
+        poses = np.array([[7.7, 0.0, 0.0], [7.72, 0.3, 0.05], [-7.7, -0.2, 3.1]])
+        scans = [synthetic.cast_scan(poses[0], ang, rng) for _ in range(2)]
+    elif scene == "one_direction":      # every beam along the same line: 1081 hits on every cell of it
+        poses = np.array([[0.3, 0.2, 0.4], [-3.0, 1.0, -2.0], [1.0, 1.0, 1.57]])
+        scans = [np.full(B, 6.0), np.full(B, 2.5)]
+        ang = np.full(B, 0.3)
+    elif scene == "tile_corner":        # 40 m tiles meet at (20, 20): the fan covers four tiles
+        poses = np.array([[19.9, 19.8, 0.7], [19.5, 19.9, -2.4], [19.99, -19.9, 1.0], [-19.9, 19.97, 0.0]])
+        scans = [5.0 + 2.5 * np.sin(4 * ang), 4.0 + 3.0 * np.cos(7 * ang) + rng.normal(0, 0.01, B)]   # smooth walls: few events per cell
+    elif scene == "negative_side":      # index-map irregularities (SURVEY quirk 3) all over the fan
+        poses = np.array([[-12.3, -15.1, 0.3], [-19.7, -3.3, 2.0], [-9.7, -9.9, -1.0], [-15.0, -19.5, 0.9]])
+        scans = [4.5 + 3.0 * np.sin(3 * ang), 3.0 + 2.0 * np.cos(5 * ang) + rng.normal(0, 0.01, B), rng.uniform(0.2, 7.0, B)]
+    else:                               # short_rays: every beam ends within 1.5 m, ~2 flagged cells per beam
+        poses = np.array([[0.0, 0.0, 0.0], [2.0, -2.0, 1.0], [-2.0, 3.0, -1.0]])
+        scans = [rng.uniform(0.3, 1.5, B), rng.uniform(0.05, 0.8, B)]
+    P = len(poses)
+    e = eng_mod.ParticleEngine(P, max_beams=B, pool_tiles=64)
+    maps = [orc.OracleHybridMap(0.05) for _ in range(P)]
+    for r in scans:
+        e.set_scan(r, ang)
+        e.map_update(poses)
+        sx, sy = orc.scan_xy(r, ang)
+        for p in range(P):
+            maps[p].update(tuple(float(v) for v in poses[p]), sx, sy)
+    for p in range(P):
+        assert_tiles_equal(e, p, oracle_dump(maps[p]), e.dim)
+    c = e.counters()
+    assert c["ray_cells_visited"] == sum(m.cells_visited for m in maps)
+    if scene == "one_direction":
+        assert c["window_fallbacks"] == P * len(scans)      # the 8-bit guard must have fired for every particle
+    if scene == "tile_corner":
+        assert c["window_fallbacks"] == 0, "fallback reasons %x" % c["cells_gathered"]
+    if scene == "negative_side":        # only the third scan (independent random ranges: too many events) may fall back
+        assert c["window_fallbacks"] <= P, "fallback reasons %x" % c["cells_gathered"]
+    e.close()
+
+
+def test_map_update_ray_cell_count_matches_oracle(eng_mod, map_kernel):
     from thesis_amd.datasets import synthetic
     B = 1081
     ang = synthetic.beam_angles(B)
@@ -160,7 +220,7 @@ def test_imu_update_golden(golden, eng_mod, model, mid):
     e.close()
 
 
-def test_map_update_full_size_properties(eng_mod):
+def test_map_update_full_size_properties(eng_mod, map_kernel):
     """BASELINE config 2 size (P=1024, B=1081): identical inputs -> identical maps; every tile equals the
     oracle's for that pose; repeating the scan saturates but never leaves [-30, 30]."""
     from thesis_amd.datasets import synthetic

@@ -35,7 +35,7 @@ class RbpfCounters(C.Structure):
         ("cells_gathered", C.c_uint64), ("tiles_in_use", C.c_uint64), ("resample_copies", C.c_uint64),
         ("bytes_copied", C.c_uint64), ("ms_raycast", C.c_double), ("ms_weight", C.c_double),
         ("ms_match", C.c_double), ("ms_resample", C.c_double), ("slow_cells", C.c_uint64),
-        ("reserved", C.c_uint64 * 7),
+        ("reserved", C.c_uint64 * 7), ("window_fallbacks", C.c_uint64),
     ]
 
 

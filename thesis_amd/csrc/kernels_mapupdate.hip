@@ -22,10 +22,7 @@
 //
 // HBM traffic: per window only the 4-byte words that contain a touched cell are read and written;
 // roofline = HBM (read-modify-write of the touched cells), no MFMA.
-#include <limits.h>
-
-#include "rbpf_internal.h"
-#include "rbpf_device.h"
+#include "rbpf_mapupdate.h"
 
 namespace rbpf {
 
@@ -37,19 +34,10 @@ namespace rbpf {
 #define STAMP(k) do { } while (0)
 #endif
 
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every
-// outstanding global load AND store; inside the window loop no thread reads or overwrites a global cell another
-// thread of the workgroup wrote in the same kernel, so the HBM read-modify-writes may stay in flight across it.
-#define BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// a value every lane agrees on, moved to a scalar register (values read from LDS are not known to be uniform)
-#define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 
 static const int MU_BLOCK = 512;       // 8 waves per particle
 static const int NB_MAX = 1536;        // bucket ids per window (flagged cells beyond it take the membership-scan path)
 static const int EV_TOT = 4096;        // event slots per window
-static const int CHUNK = 16;           // ray steps per work item of the walk
-
 __host__ __device__ inline int mu_fan_width(int reach) { return (2 * reach + 8 + 7) & ~7; }
 __host__ __device__ inline int mu_nb(int B) { int nb = 2 * B; return nb < NB_MAX ? nb : NB_MAX; }
 // chunk table entries: every ray has at most ceil((WIN + 2) / CHUNK) = 9 chunks in a window; the same memory later
@@ -64,8 +52,6 @@ size_t raycast_lds_bytes(int B, int reach) {
     return (bytes + 15) & ~(size_t)15;
 }
 
-// per-ray info byte
-enum { RI_VALID = 1, RI_OCC = 2, RI_NEAR = 4 };   // bits 3-4: near dx + 1, bits 5-6: near dy + 1
 
 struct MuLds {
     uint32_t* cnt;    // [WIN*WIN/2] two 16-bit hit counters per word; flagged cells hold their bucket id
@@ -88,45 +74,6 @@ __device__ __forceinline__ uint32_t cnt16_get(const uint32_t* cnt, int c) { retu
 __device__ __forceinline__ void cnt16_set(uint32_t* cnt, int c, uint32_t val) { reinterpret_cast<uint16_t*>(cnt)[c] = (uint16_t)val; }
 __device__ __forceinline__ bool flag_get(const uint32_t* flag, int c) { return (flag[c >> 5] >> (c & 31)) & 1u; }
 
-// same-tile test of hybridmap.py:141 (m.is_in_map(nearby_pos) with m = tile of the end cell)
-__device__ __forceinline__ bool same_tile(const DevView& v, int xa, int ya, int xb, int yb) {
-    return lut_lat(lut_at(v, xa)) == lut_lat(lut_at(v, xb)) && lut_lat(lut_at(v, ya)) == lut_lat(lut_at(v, yb));
-}
-
-// wave-level reductions (all 64 lanes take part): one LDS atomic per wave instead of one per lane
-__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
-__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; }
-__device__ __forceinline__ int wave_sum(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
-__device__ __forceinline__ int wave_excl_scan(int v, int lane) {   // exclusive prefix sum over the wave
-    int incl = v;
-    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
-    return incl - v;
-}
-
-// first j with minor offset >= m (m >= 1, dmin > 0), 32-bit (2*dmaj*m < 2^31 for rays shorter than a tile)
-__device__ __forceinline__ int first_j_minor_ge(const Ray& r, int m) {
-    int num = 2 * r.dmaj * m - r.dmaj, den = 2 * r.dmin;
-    return (num + den - 1) / den;
-}
-__device__ __forceinline__ int last_j_minor_le(const Ray& r, int m) {
-    int num = 2 * r.dmaj * (m + 1) - r.dmaj - 1;
-    if (num < 0) return -1;
-    int j = num / (2 * r.dmin);
-    return j > r.dmaj ? r.dmaj : j;
-}
-
-// Clamped-add functions v -> min(max(v + a, lo), hi) are closed under composition, so the ordered sequence of
-// a cell's events folds associatively: each lane folds the events of one beam, the wave folds 64 beams in
-// beam order with a shuffle tree.
-struct Caf { int a, lo, hi; };
-__device__ __forceinline__ Caf caf_then(Caf f, Caf g) {          // g after f
-    Caf r;
-    r.a = f.a + g.a;
-    int lo = f.lo + g.a; lo = lo < g.lo ? g.lo : lo; r.lo = lo > g.hi ? g.hi : lo;
-    int hi = f.hi + g.a; hi = hi < g.lo ? g.lo : hi; r.hi = hi > g.hi ? g.hi : hi;
-    return r;
-}
-__device__ __forceinline__ int caf_apply(Caf f, int x) { int t = x + f.a; t = t < f.lo ? f.lo : t; return t > f.hi ? f.hi : t; }
 
 // first global index g in [lo, hi] whose storage index fan[g - f0] is >= target (hi + 1 if none), from a close guess
 __device__ __forceinline__ int fan_first_ge(const uint16_t* fan, int f0, int lo, int hi, int target, int guess) {
@@ -150,85 +97,11 @@ __device__ __forceinline__ void walk_flagged(const MuLds& s, int cc, uint32_t hv
     }
 }
 
-// One lane replays a bucket of up to N events: bitonic sorting network on registers (padded with 0xFFFF), then the
-// clamped adds in ascending (beam, rank) order.
-template <int N>
-__device__ __forceinline__ int replay_sorted(const uint16_t* __restrict__ evp, int m, int val, const CellConsts& cc) {
-    uint32_t ev[N];
-#pragma unroll
-    for (int e = 0; e < N; ++e) ev[e] = e < m ? (uint32_t)evp[e] : 0xFFFFu;
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t a = ev[i], b = ev[l];
-                    const bool up = (i & k) == 0;
-                    ev[i] = up ? min(a, b) : max(a, b);
-                    ev[l] = up ? max(a, b) : min(a, b);
-                }
-            }
-#pragma unroll
-    for (int e = 0; e < N; ++e)
-        if (e < m) val = cell_apply_rank(val, (int)(ev[e] & 7u), cc);
-    return val;
-}
 
-__device__ int replay_cell_wave(const DevView& v, const MuLds& s, int x0, int y0, const int* gxc, int ngx,
-                                const int* gyc, int ngy, int val, int lane) {
-    const int BIG = 1000000;
-    const Caf fE = {v.cc.emp, v.cc.vmin, BIG}, fO = {v.cc.occ, -BIG, v.cc.vmax}, fN = {v.cc.nearby, -BIG, v.cc.vmax};
-    for (int base = 0; base < v.B; base += 64) {
-        const int b = base + lane;
-        Caf f = {0, -BIG, BIG};
-        bool has = false;
-        if (b < v.B && (s.r_info[b] & RI_VALID)) {
-            const int info = s.r_info[b];
-            int x1, y1;
-            unpack_end(s.r_end[b], x0, y0, x1, y1);
-            Ray r = ray_make(x0, y0, x1, y1);
-            const bool occ = info & RI_OCC;
-            int js[4], nj = 0;
-            for (int ix = 0; ix < ngx; ++ix)
-                for (int iy = 0; iy < ngy; ++iy) {
-                    int gx = gxc[ix], gy = gyc[iy];
-                    int j = r.steep ? (gy - y0) * r.sy : (gx - x0) * r.sx;
-                    if (j < 0 || j >= r.n) continue;
-                    int qx, qy;
-                    ray_point(r, j, qx, qy);
-                    if (qx == gx && qy == gy) js[nj++] = j;
-                }
-            for (int a = 1; a < nj; ++a) {
-                int key = js[a], c = a - 1;
-                while (c >= 0 && js[c] > key) { js[c + 1] = js[c]; --c; }
-                js[c + 1] = key;
-            }
-            bool near_here = false;
-            for (int a = 0; a < nj; ++a) {
-                int j = js[a];
-                f = caf_then(f, (j == r.n - 1 && occ) ? fO : fE);
-                if (j == r.n - 2 && (info & RI_NEAR)) near_here = true;
-            }
-            if (near_here) f = caf_then(f, fN);
-            has = nj > 0;
-        }
-        if (__ballot(has) == 0ull) continue;
-        for (int off = 1; off < 64; off <<= 1) {
-            Caf g;
-            g.a = __shfl_down(f.a, off, 64); g.lo = __shfl_down(f.lo, off, 64); g.hi = __shfl_down(f.hi, off, 64);
-            if ((lane & (2 * off - 1)) == 0) f = caf_then(f, g);
-        }
-        val = caf_apply(f, val);        // lane 0 holds the fold of the whole chunk
-        val = __shfl(val, 0, 64);
-    }
-    return val;
-}
-
-__global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   // 2 workgroups per CU
+// only != nullptr: process just the particles the whole-fan kernel gave back (only[p] != 0)
+__global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v, const int32_t* __restrict__ only) {   // 2 workgroups per CU
     extern __shared__ __align__(16) unsigned char smem[];
+    if (only && !only[blockIdx.x]) return;
     const int NB = mu_nb(v.B);
     MuLds s;
     s.cnt = reinterpret_cast<uint32_t*>(smem);
@@ -739,7 +612,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
                     int gxc[4], gyc[4], ngx = 0, ngy = 0;
                     for (int i = 0; i < nx_ && ngx < 4; ++i) if ((int)lutx[i] - wx0 == lx) gxc[ngx++] = gxa + i;
                     for (int i = 0; i < ny_ && ngy < 4; ++i) if ((int)luty[i] - wy0 == ly) gyc[ngy++] = gya + i;
-                    int val = replay_cell_wave(v, s, x0, y0, gxc, ngx, gyc, ngy,
+                    int val = replay_cell_wave(v, s.r_info, s.r_end, x0, y0, gxc, ngx, gyc, ngy,
                                                (int)tile_base[(size_t)(wx0 + lx) * v.dim + (wy0 + ly)], lane);
                     if (lane == 0) cnt16_set(s.cnt, c, 0x8000u | ((uint32_t)val & 0xFFu));
                 }
@@ -822,6 +695,7 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v) {   
         }
     }
     if (tid == 0) {
+        if (only) atomicAdd(&v.stats[ST_WINDOW_FALLBACKS], 1ull);
         if (s_cells) atomicAdd(&v.stats[ST_RAY_CELLS], s_cells);
         if (s_tot_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_tot_written);
         if (s_tot_slow) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)s_tot_slow);
@@ -839,7 +713,9 @@ void launch_map_update_fused(const DevView& v, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v);
+    const bool fan = v.mu_mode == 0 && map_update_fan_available(v);
+    if (fan) launch_map_update_fan(v, s);
+    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr);
 }
 
 }  // namespace rbpf

@@ -3,6 +3,7 @@
 // runs in the gfx950 kernels of kernels_*.hip; there is no CPU compute path.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -206,6 +207,11 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, btmp, (size_t)c.max_beams); v.bflags = btmp;
         ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.n_items, 2);
         ALLOC(h, v.stats, 16); ALLOC(h, v.err, 1);
+        ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
+        {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle (tests, comparisons)
+            const char* mk = getenv("RBPF_MAP_KERNEL");
+            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
+        }
         ALLOC(h, v.msel_x, (size_t)c.max_beams); ALLOC(h, v.msel_y, (size_t)c.max_beams);
         ALLOC(h, v.asel_x, (size_t)c.max_beams); ALLOC(h, v.asel_y, (size_t)c.max_beams);
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
@@ -322,8 +328,10 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.cells_gathered = st[ST_GATHERS]; c.slow_cells = st[ST_SLOW_CELLS];
     c.resample_copies = st[ST_COPIES]; c.bytes_copied = st[ST_COPY_BYTES];
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
+    c.window_fallbacks = st[ST_WINDOW_FALLBACKS];
     for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];
-    c.cells_gathered = st[15];                                  // eighth stamp slot of a diagnostic build      // phase cycle sums of a -DRBPF_STAMPS diagnostic build
+    // diagnostic slot: four 16-bit tallies of whole-fan fallback reasons, or the eighth phase stamp of a -DRBPF_STAMPS build
+    c.cells_gathered = st[15] ? st[15] : st[ST_FALLBACK_REASONS];
     if (h->profiling) {
         double* dst[4] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match};
         for (int k = 0; k < 4; ++k) {

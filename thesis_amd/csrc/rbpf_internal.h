@@ -56,6 +56,8 @@ struct DevView {
     int32_t* ray_start;                // [P][2] start cell, or INT_MIN when the particle is skipped
     int32_t* items;                    // [P*MAX_ITEMS][4] particle, pool tile, wx0 | wy0<<16, lat x | lat y<<16
     int32_t* n_items;                  // [1]
+    int32_t* mu_fallback;              // [P] 1 = the whole-fan map update gave the particle back to the window kernel
+    int mu_mode;                       // 0 = whole-fan kernel when the layout allows it, 1 = 128x128 windows only
     unsigned long long* stats;         // [8] device counters
     int32_t* err;                      // [1] sticky device error code
 };
@@ -70,7 +72,7 @@ struct ResampleBuffers {
 };
 
 enum { ST_RAY_CELLS = 0, ST_CELLS_WRITTEN = 1, ST_GATHERS = 2, ST_SLOW_CELLS = 3,
-       ST_COPIES = 4, ST_COPY_BYTES = 5 };
+       ST_COPIES = 4, ST_COPY_BYTES = 5, ST_WINDOW_FALLBACKS = 6, ST_FALLBACK_REASONS = 7 };
 
 }  // namespace rbpf
 
@@ -109,7 +111,9 @@ namespace rbpf {
 // kernel launchers (one translation unit per kernel family)
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
-void launch_map_update_fused(const DevView& v, hipStream_t s);
+void launch_map_update_fused(const DevView& v, hipStream_t s);   // picks the kernel(s) below
+bool map_update_fan_available(const DevView& v);
+void launch_map_update_fan(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
 void launch_imu_update(const DevView& v, int model, double d0, double d1, double d2, double dt_ticks,
