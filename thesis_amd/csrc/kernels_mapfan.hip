@@ -99,6 +99,24 @@ bool map_update_fan_available(const DevView& v) {
     return fan_geom(v.B, v.reach).ok && v.dim % 32 == 0 && v.L * v.L <= 49 && sat <= 64 && v.cc.emp < 0 && v.cc.vmax - v.cc.vmin <= 127;
 }
 
+// atomicAdd(&arr[key], 1) for every lane with valid = true, one LDS atomic per distinct key in the wave (a handful of
+// keys shared by many lanes would otherwise serialise); returns the value the lane's own add would have returned.
+__device__ __forceinline__ int wave_keyed_inc(int* arr, int key, bool valid, int lane) {
+    int res = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(valid && key == k);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&arr[k], __popcll(same));
+        base = __shfl(base, leader, 64);
+        if (valid && key == k) res = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return res;
+}
+
 // 8-bit / 16-bit hit-counter fields packed into 32-bit LDS words
 template <bool MINI> struct Fld;
 template <> struct Fld<false> {
@@ -165,18 +183,43 @@ __device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* 
                 }
         }
     }
-    for (; j <= jhi; ++j) {
-        const int c1 = c;
-        if (D >= 0) { c += dminc; D -= dmaj2; }
-        D += dmin2; c += dmajc;
-        const uint32_t f = (atomicAdd(cw + F::word(c1), 1u << F::sh(c1)) >> F::sh(c1)) & F::MASK;
-        if (!MINI) guard |= f & (f << 1);
-        if (f & F::FLAG) {
+    if (j <= jhi) {                                                        // one to three steps left: one masked group
+        int cc[3]; uint32_t h[3]; uint32_t* ap[3]; uint32_t av[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            cc[u] = c;
+            if (D >= 0) { c += dminc; D -= dmaj2; }
+            D += dmin2; c += dmajc;
+            if (j + u > jhi) cc[u] = cc[0];                                // dead step: a valid address, nothing added
+        }
+        if (SAT) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) h[u] = cw[F::word(cc[u])];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            bool skip = j + u > jhi;
+            if (SAT) { const uint32_t f = (h[u] >> F::sh(cc[u])) & F::MASK; skip = skip || (f - sat < F::FLAG - sat); }
+            ap[u] = skip ? sink : cw + F::word(cc[u]);
+            av[u] = skip ? 0u : 1u << F::sh(cc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) h[u] = atomicAdd(ap[u], av[u]);
+        uint32_t any = 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            h[u] = av[u] ? (h[u] >> F::sh(cc[u])) & F::MASK : 0u;
+            any |= h[u];
+            if (!MINI) guard |= h[u] & (h[u] << 1);
+        }
+        if (any & F::FLAG) {
             hit = true;
-            if (near_ok && n - 1 - j == 1) {
-                const uint32_t f2 = (atomicAdd(cw + F::word(c1), 1u << F::sh(c1)) >> F::sh(c1)) & F::MASK;
-                if (!MINI) guard |= f2 & (f2 << 1);
-            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if ((h[u] & F::FLAG) && near_ok && n - 1 - (j + u) == 1) {
+                    const uint32_t f2 = (atomicAdd(cw + F::word(cc[u]), 1u << F::sh(cc[u])) >> F::sh(cc[u])) & F::MASK;
+                    if (!MINI) guard |= f2 & (f2 << 1);
+                }
         }
     }
 }
@@ -207,8 +250,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     uint32_t* const dummy = reinterpret_cast<uint32_t*>(smem + G.o_dummy); // per-lane sink for skipped adds
     uint16_t* const bev = reinterpret_cast<uint16_t*>(smem + G.o_bev);     // [FEV] (beam << 3) | rank
 
-    __shared__ double s_c, s_s, s_px, s_py;
-    __shared__ int s_x0, s_y0, s_skip, s_fb;
+    __shared__ int s_fb;
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];
     __shared__ int s_cntc[MAXLEV + 1], s_fill[MAXLEV + 1], s_lp[MAXLEV + 1], s_nk[MAXLEV + 1];
@@ -225,39 +267,65 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
 #endif
     // =============================================== setup ===============================================
-    if (tid == 0) {
-        double px = v.upd_pose[p], py = v.upd_pose[v.P + p], th = v.upd_pose[2 * v.P + p];
-        double sn, cs;
-        sincos(th, &sn, &cs);
-        s_c = cs; s_s = sn; s_px = px; s_py = py;
-        int x0 = trunc_to_int(px / v.cs), y0 = trunc_to_int(py / v.cs);      // hybridmap.py:102
-        s_x0 = x0; s_y0 = y0;
+    // Every thread derives the pose quantities itself (same inputs, same arithmetic): no broadcast, no barrier.
+    // this thread's first two beams: loaded before anything else so that the latency overlaps the pose arithmetic
+    const int pb0 = tid, pb1 = tid + FB;
+    const double pre_x0 = pb0 < v.B ? v.bx[pb0] : 0.0, pre_y0 = pb0 < v.B ? v.by[pb0] : 0.0;
+    const double pre_x1 = pb1 < v.B ? v.bx[pb1] : 0.0, pre_y1 = pb1 < v.B ? v.by[pb1] : 0.0;
+    const int pre_f0 = pb0 < v.B ? v.bflags[pb0] : 0, pre_f1 = pb1 < v.B ? v.bflags[pb1] : 0;
+    const double s_px = v.upd_pose[p], s_py = v.upd_pose[v.P + p];
+    double s_s, s_c;
+    sincos(v.upd_pose[2 * v.P + p], &s_s, &s_c);
+    const int x0 = UNI(trunc_to_int(s_px / v.cs)), y0 = UNI(trunc_to_int(s_py / v.cs));   // hybridmap.py:102
+    {
         int lx, ly;                                                          // hybridmap.py:98-100
-        bool ok = tile_of_coord(px, v.tile_len, v.R, lx) && tile_of_coord(py, v.tile_len, v.R, ly);
+        bool ok = tile_of_coord(s_px, v.tile_len, v.R, lx) && tile_of_coord(s_py, v.tile_len, v.R, ly);
         if (ok) ok = tab[(lx + v.R) * v.L + (ly + v.R)] >= 0;
-        const int reach = v.reach;
-        bool in_lut = lut_valid_g(v, x0 - reach) && lut_valid_g(v, x0 + reach) &&
-                      lut_valid_g(v, y0 - reach) && lut_valid_g(v, y0 + reach);
-        if (ok && !in_lut) { atomicCAS(v.err, 0, RBPF_ERANGE); ok = false; }
-        s_skip = ok ? 0 : 1;
+        const bool in_lut = lut_valid_g(v, x0 - v.reach) && lut_valid_g(v, x0 + v.reach) &&
+                            lut_valid_g(v, y0 - v.reach) && lut_valid_g(v, y0 + v.reach);
+        if (ok && !in_lut) { if (tid == 0) atomicCAS(v.err, 0, RBPF_ERANGE); ok = false; }
+        if (tid == 0) v.mu_fallback[p] = 0;
+        if (!UNI(ok)) return;
+    }
+    // the index map over everything a ray can reach: U of global column fxl + i (fyl + i), i <= 2 * reach
+    const int fxl = x0 - v.reach, fyl = y0 - v.reach, nfx = 2 * v.reach + 1, nfy = nfx;
+    for (int i = tid; i < G.fanw; i += FB) {
+        const int gxq = fxl + i, gyq = fyl + i;
+        uint32_t ex = lut_valid_g(v, gxq) ? lut_at(v, gxq) : LUT_INVALID, ey = lut_valid_g(v, gyq) ? lut_at(v, gyq) : LUT_INVALID;
+        ux[i] = ex != LUT_INVALID ? (uint16_t)(lut_lat(ex) * v.dim + lut_cidx(ex)) : 0xFFFFu;
+        uy[i] = ey != LUT_INVALID ? (uint16_t)(lut_lat(ey) * v.dim + lut_cidx(ey)) : 0xFFFFu;
+    }
+    if (tid == 0) {
         s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
         s_cells = 0; s_fb = 0; s_written = 0;
         s_nflag = 0; s_nmark = 0; s_nbig = 0; s_nslow = 0; s_ev = 0;
-        v.mu_fallback[p] = 0;
     }
-    if (tid <= MAXLEV) s_cntc[tid] = 0;
+    if (tid <= MAXLEV) { s_cntc[tid] = 0; s_fill[tid] = 0; }
     for (int i = tid; i < LL; i += FB) { s_need[i] = 0; s_tab[i] = tab[i]; }
+    {   // clear the counters (independent of everything above: overlaps the LUT reads)
+        uint4* c4 = reinterpret_cast<uint4*>(smem + G.o_cnt);
+        const int n16 = (G.o_mini - G.o_cnt) >> 4;                           // counters and directory are adjacent
+        for (int i = tid; i < n16; i += FB) c4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < (MINI_W * MINI_W + 1) / 2; i += FB) mini[i] = 0;
+        if (tid < 64) dummy[tid] = 0;
+    }
     __syncthreads();
-    if (s_skip) return;
+    STAMP(7);
 
-    const int x0 = UNI(s_x0), y0 = UNI(s_y0);
-    const int a0 = lut_lat(lut_at(v, x0)), b0 = lut_lat(lut_at(v, y0));
+    // lattice coordinate (biased) of a column of the LUT: rays are shorter than a tile, so it is the start tile's or a neighbour's
+    const int Uxs = UNI(ux[x0 - fxl]), Uys = UNI(uy[y0 - fyl]);
+    const int a0 = Uxs / v.dim, b0 = Uys / v.dim;
+    auto lat_x = [&](int g) { const int U = ux[g - fxl]; return a0 + (U >= (a0 + 1) * v.dim ? 1 : 0) - (U < a0 * v.dim ? 1 : 0); };
+    auto lat_y = [&](int g) { const int U = uy[g - fyl]; return b0 + (U >= (b0 + 1) * v.dim ? 1 : 0) - (U < b0 * v.dim ? 1 : 0); };
     {
         unsigned long long my_cells = 0;
         int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
-        for (int b = tid; b < v.B; b += FB) {
-            const double x = v.bx[b], y = v.by[b];
-            const int bf = v.bflags[b];
+        for (int b0_ = 0; b0_ < v.B; b0_ += FB) {                                   // wave-uniform trip count (wave_keyed_inc)
+            const int b = b0_ + tid;
+            int nch_b = 0;
+            if (b < v.B) {
+            const double x = b == pb0 ? pre_x0 : b == pb1 ? pre_x1 : v.bx[b], y = b == pb0 ? pre_y0 : b == pb1 ? pre_y1 : v.by[b];
+            const int bf = b == pb0 ? pre_f0 : b == pb1 ? pre_f1 : (int)v.bflags[b];
             double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
             double gy = (s_s * x + s_c * y) + s_py;
             int x1 = trunc_to_int(gx / v.cs), y1 = trunc_to_int(gy / v.cs);        // hybridmap.py:106
@@ -278,15 +346,15 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                 info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
                 my_cells += (unsigned long long)r.n;
                 fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
+                const int a1 = lat_x(x1), b1 = lat_y(y1);
                 if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
                     int nx, ny;
                     ray_point(r, r.n - 2, nx, ny);
-                    if (same_tile(v, nx, ny, x1, y1)) info |= RI_NEAR;
+                    if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;      // hybridmap.py:141 same tile as the end cell
                     info |= ((nx - x1 + 1) & 3) << 3;
                     info |= ((ny - y1 + 1) & 3) << 5;
                 }
                 // tiles entered by this ray (staircase start -> [corner] -> end)
-                const int a1 = lut_lat(lut_at(v, x1)), b1 = lut_lat(lut_at(v, y1));
                 s_need[a0 * v.L + b0] = 1;
                 if (a1 != a0 || b1 != b0) {
                     s_need[a1 * v.L + b1] = 1;
@@ -301,9 +369,11 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                         else if (jy < jx) s_need[a0 * v.L + b1] = 1;
                     }
                 }
-                atomicAdd(&s_cntc[(r.n + CHUNK - 1) / CHUNK], 1);
             }
             r_info[b] = (uint8_t)info;
+            nch_b = (r.n + CHUNK - 1) / CHUNK;
+            }
+            wave_keyed_inc(s_cntc, nch_b, nch_b > 0, lane);
         }
         {
             const int ws = wave_sum((int)my_cells);
@@ -315,26 +385,39 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             }
         }
     }
+    // irregular steps of the index map (U(g+1) - U(g) != 1) before each column: the last two waves, x and y
+    if (wave >= FB / 64 - 2) {
+        const bool isy = wave == FB / 64 - 1;
+        const uint16_t* uu = isy ? uy : ux;
+        uint8_t* gp = isy ? gpy : gpx;
+        const int per = (G.fanw + 63) / 64, i0 = lane * per;
+        int loc = 0;
+        for (int i = i0; i < i0 + per; ++i) if (i + 1 < nfx && (int)uu[i + 1] - (int)uu[i] != 1) ++loc;
+        int run = wave_excl_scan(loc, lane);
+        for (int i = i0; i < i0 + per && i < G.fanw; ++i) {
+            gp[i] = (uint8_t)run;
+            if (run > 255) s_fb = 1;                                         // cannot be told apart in 8 bits
+            if (i + 1 < nfx && (int)uu[i + 1] - (int)uu[i] != 1) ++run;
+        }
+    }
     __syncthreads();
-    const int fxl = UNI(s_fan[0]), fxh = UNI(s_fan[1]), fyl = UNI(s_fan[2]), fyh = UNI(s_fan[3]);
-    const int nfx = fxh - fxl + 1, nfy = fyh - fyl + 1;                      // <= 2*reach + 1 <= fanw
-    // rays ordered by falling chunk count: the rays that own a k-th chunk are perm[0 .. N_k)
-    if (tid == 0) {
+    // ---- the window: the fan's bounding box in U coordinates ----
+    const int bxl = UNI(s_fan[0]), bxh = UNI(s_fan[1]), byl = UNI(s_fan[2]), byh = UNI(s_fan[3]);
+    const int Ux0 = UNI(ux[bxl - fxl]), Uy0al = UNI(uy[byl - fyl] & ~3);
+    const int rows_u = UNI(ux[bxh - fxl]) - Ux0 + 1, cols_u = UNI(uy[byh - fyl]) - Uy0al + 1;
+    const int stride = (cols_u + 3) & ~3;                                      // this particle's window: rows_u x stride cells
+    const int wxc = Uxs - Ux0, wyc = Uys - Uy0al;                              // the start cell in window coordinates
+    const int total_irreg = UNI((int)gpx[bxh - fxl] - (int)gpx[bxl - fxl] + (int)gpy[byh - fyl] - (int)gpy[byl - fyl]);
+    if (rows_u * stride > G.ncell || rows_u < 1 || cols_u < 1 || UNI(s_fb)) { GIVE_BACK(1); }
+    if (tid == 0) {   // level table: a level's items are padded to whole waves; lane l of a wave takes ray
+                      // l * (waves of the level) + wave, so that the lanes of one LDS instruction touch cells far apart
         int cntc[MAXLEV + 1];
         for (int c = 0; c <= MAXLEV; ++c) cntc[c] = s_cntc[c];
-        int above = 0;
-        for (int c = MAXLEV; c >= 1; --c) { s_fill[c] = above; above += cntc[c]; }
-        int lp = 0, nk = above;                                              // nk = rays with more than k chunks
-        // a level's items are padded to whole waves: lane l of a wave takes ray l * (waves of the level) + wave, so
-        // that the lanes of one LDS instruction touch cells far apart
+        int nk = 0;
+        for (int c = 1; c <= MAXLEV; ++c) nk += cntc[c];                     // nk = rays with more than k chunks
+        int lp = 0;
         for (int k = 0; k < MAXLEV; ++k) { s_lp[k] = lp; s_nk[k] = nk; lp += (nk + 63) & ~63; nk -= cntc[k + 1]; }
         s_lp[MAXLEV] = lp;
-    }
-    for (int i = tid; i < G.fanw; i += FB) {
-        const int gxq = fxl + i, gyq = fyl + i;
-        uint32_t ex = lut_valid_g(v, gxq) ? lut_at(v, gxq) : LUT_INVALID, ey = lut_valid_g(v, gyq) ? lut_at(v, gyq) : LUT_INVALID;
-        ux[i] = ex != LUT_INVALID ? (uint16_t)(lut_lat(ex) * v.dim + lut_cidx(ex)) : 0xFFFFu;
-        uy[i] = ey != LUT_INVALID ? (uint16_t)(lut_lat(ey) * v.dim + lut_cidx(ey)) : 0xFFFFu;
     }
     if (tid < LL && s_need[tid] && s_tab[tid] < 0) {                         // allocate missing tiles (kept zero-filled)
         int idx = atomicSub(v.free_top, 1) - 1;
@@ -350,47 +433,23 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             v.tile_bbox[4 * t + 2] = INT_MAX; v.tile_bbox[4 * t + 3] = -1;
         }
     }
-    // ---- clear the counters
-    {
-        uint4* c4 = reinterpret_cast<uint4*>(smem + G.o_cnt);
-        const int n16 = (G.o_mini - G.o_cnt) >> 4;                           // counters and directory are adjacent
-        for (int i = tid; i < n16; i += FB) c4[i] = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < (MINI_W * MINI_W + 1) / 2; i += FB) mini[i] = 0;
-        if (tid < 64) dummy[tid] = 0;
-    }
-    __syncthreads();
-    for (int b = tid; b < v.B; b += FB) {
-        const int info = r_info[b];
-        if (!(info & RI_VALID)) continue;
-        int x1, y1;
-        unpack_end(r_end[b], x0, y0, x1, y1);
-        const Ray r = ray_make(x0, y0, x1, y1);
-        const int nch = (r.n + CHUNK - 1) / CHUNK;
-        perm[atomicAdd(&s_fill[nch], 1)] = (uint16_t)b;
-    }
-    // irregular steps of the index map (U(g+1) - U(g) != 1) before each column: wave 0 for x, wave 1 for y
-    if (wave < 2) {
-        const uint16_t* uu = wave ? uy : ux;
-        uint8_t* gp = wave ? gpy : gpx;
-        const int nn = wave ? nfy : nfx;
-        const int per = (G.fanw + 63) / 64, i0 = lane * per;
-        int loc = 0;
-        for (int i = i0; i < i0 + per; ++i) if (i + 1 < nn && (int)uu[i + 1] - (int)uu[i] != 1) ++loc;
-        int run = wave_excl_scan(loc, lane);
-        for (int i = i0; i < i0 + per && i < G.fanw; ++i) {
-            gp[i] = (uint8_t)run;
-            if (run > 255) s_fb = 1;                                         // cannot be told apart in 8 bits
-            if (i + 1 < nn && (int)uu[i + 1] - (int)uu[i] != 1) ++run;
+    // rays ordered by falling chunk count: the rays that own a k-th chunk are perm[0 .. N_k)
+    for (int b0_ = 0; b0_ < v.B; b0_ += FB) {
+        const int b = b0_ + tid;
+        int nch = 0;
+        if (b < v.B && (r_info[b] & RI_VALID)) {
+            int x1, y1;
+            unpack_end(r_end[b], x0, y0, x1, y1);
+            const Ray r = ray_make(x0, y0, x1, y1);
+            nch = (r.n + CHUNK - 1) / CHUNK;
+        }
+        const int pos = wave_keyed_inc(s_fill, nch, nch > 0, lane);
+        if (nch > 0) {
+            int start = 0;
+            for (int c = nch + 1; c <= MAXLEV; ++c) start += s_cntc[c];
+            perm[start + pos] = (uint16_t)b;
         }
     }
-    const int Ux0 = UNI(ux[0]), Uy0al = UNI(uy[0] & ~3);
-    const int rows_u = UNI(ux[nfx - 1]) - Ux0 + 1, cols_u = UNI(uy[nfy - 1]) - Uy0al + 1;
-    const int stride = (cols_u + 3) & ~3;                                      // this particle's window: rows_u x stride cells
-    const int wxc = UNI(ux[x0 - fxl]) - Ux0, wyc = UNI(uy[y0 - fyl]) - Uy0al;   // the start cell in window coordinates
-    if (tid == 0 && (rows_u * stride > G.ncell || rows_u < 1 || cols_u < 1 || nfx > G.fanw || nfy > G.fanw)) s_fb = 1;
-    BAR_LDS();
-    const int total_irreg = UNI((int)gpx[nfx - 1] + (int)gpy[nfy - 1]);
-    if (UNI(s_fb)) { GIVE_BACK(1); }
 
     // window coordinates of a global cell of the fan / field helpers
     auto in_mini = [&](int wx, int wy) { return (unsigned)(wx - wxc + MINI_R) < (unsigned)MINI_W && (unsigned)(wy - wyc + MINI_R) < (unsigned)MINI_W; };

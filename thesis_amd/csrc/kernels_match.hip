@@ -103,6 +103,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     s.sc = reinterpret_cast<int*>(s.cy8 + cap8);
     __shared__ double s_g[3], s_rng[2];
     __shared__ int s_org[2], s_nb, s_best, s_bestc;
+    __shared__ unsigned s_def[32], s_slowg;  // per region word: defect columns of the index map; words not inside one mapped tile
     __shared__ double s_mom[10], s_wmom[MBLOCK / 64][10];
     __shared__ int s_tab[49];
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         s_g[0] = gx; s_g[1] = gy; s_g[2] = gth; s_rng[0] = rx; s_rng[1] = ry;
         s_org[0] = (int)floor(gx / a.mcs) - N / 2;
         s_org[1] = (int)floor(gy / a.mcs) - N / 2;
-        s_nb = 0; s_best = INT_MIN; s_bestc = 0;
+        s_nb = 0; s_best = INT_MIN; s_bestc = 0; s_slowg = 0;
         for (int i = 0; i < 10; ++i) s_mom[i] = 0.0;
     }
     if (!a.single) {
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         for (int i = tid; i < v.L * v.L; i += MBLOCK) s_tab[i] = tab[i];
     }
     for (int i = tid; i < N * W; i += MBLOCK) { s.occ[i] = 0; s.dil[i] = 0; }
+    if (tid < 32) s_def[tid] = 0;
     for (int i = tid; i < (N / M_COARSE) * match_crs_words(N); i += MBLOCK) s.crs[i] = 0;
     __syncthreads();
     const int ox = s_org[0], oy = s_org[1];
@@ -146,30 +148,44 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         for (int i = tid; i < N * a.ds; i += MBLOCK) {
             const int gyi = oy * a.ds + i, gxi = ox * a.ds + i;
             int16_t e = -1;
-            if (lut_valid_g(v, gyi)) { const uint32_t ey = lut_at(v, gyi); e = (int16_t)((lut_lat(ey) << 12) | lut_cidx(ey)); }
+            if (lut_valid_g(v, gyi)) {
+                const uint32_t ey = lut_at(v, gyi);
+                e = (int16_t)((lut_lat(ey) << 12) | lut_cidx(ey));
+                // the reference's float index formula is the plain cell arithmetic except at isolated
+                // columns: those are this word's defect bits
+                if (lut_cidx(ey) != gyi - (lut_lat(ey) - v.R) * v.dim + v.dim / 2) atomicOr(&s_def[(i >> 5) & 31], 1u << (i & 31));
+                const int g0 = gyi - (i & 31);                  // the word's first column: must be the same tile
+                if ((i & 31) && !(lut_valid_g(v, g0) && lut_lat(lut_at(v, g0)) == lut_lat(ey))) atomicOr(&s_slowg, 1u << ((i >> 5) & 31));
+            } else atomicOr(&s_slowg, 1u << ((i >> 5) & 31));
             colmap[i] = e;
             uint32_t rb = 0xFFFFFFFFu;                          // high byte = lattice row of the tile table, low 24 bits = storage row
             if (lut_valid_g(v, gxi)) { const uint32_t ex = lut_at(v, gxi); rb = ((uint32_t)lut_lat(ex) << 24) | (uint32_t)lut_cidx(ex); }
             rowbase[i] = rb;
         }
         __syncthreads();
-        for (int q0 = tid; q0 < N * W; q0 += 4 * MBLOCK) {
-            uint32_t lo[4], hi[4], hi2[4]; int sh[4]; bool fast[4];
+        MSTAMP(6);
+        // One region word (32 columns of one row) per lane.  A wave takes 16 rows x 4 adjacent words, so that the words
+        // with many defect columns meet in few waves and the loads of a row stay contiguous.
+        const int WP = (W + 3) & ~3, GT = WP / 4;
+        const unsigned slowg = (a.ds != 1 || W > 32) ? 0xFFFFFFFFu : s_slowg;
+        for (int q0 = tid; q0 < N * WP; q0 += 4 * MBLOCK) {
+            uint32_t lo[4], hi[4], hi2[4]; int sh[4], c0r[4], uu[4], ww[4]; bool fast[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                       // issue the mask loads of four words first
                 const int q = q0 + k * MBLOCK;
-                lo[k] = hi[k] = hi2[k] = 0; sh[k] = 0; fast[k] = false;
-                if (q >= N * W || a.ds != 1) continue;
-                const int u = q / W, wv = q % W;
+                const int blk = q >> 6, l = q & 63;
+                const int u = (blk / GT) * 16 + (l & 15), wv = (blk % GT) * 4 + (l >> 4);
+                uu[k] = u; ww[k] = (q < N * WP && wv < W) ? wv : -1;
+                lo[k] = hi[k] = hi2[k] = 0; sh[k] = 0; c0r[k] = 0; fast[k] = false;
+                if (ww[k] < 0 || ((slowg >> wv) & 1u)) continue;
                 const uint32_t rb = rowbase[u];
-                const int e0 = colmap[wv * 32], e1 = colmap[wv * 32 + 31];
-                // 32 region columns of one tile whose storage columns lie in [e0-1, e0+33]: the isolated off-by-one
-                // glitches of the reference's index formula keep every column inside a 96-bit window
-                if (rb == 0xFFFFFFFFu || e0 < 0 || e1 < 0 || (e0 >> 12) != (e1 >> 12) || e1 - e0 > 33 || e1 - e0 < 29) continue;
+                if (rb == 0xFFFFFFFFu) continue;
                 fast[k] = true;
-                const int t = s_tab[(rb >> 24) * v.L + (e0 >> 12)];
+                const int lat = colmap[wv * 32] >> 12;
+                const int t = s_tab[(rb >> 24) * v.L + lat];
                 if (t < 0) continue;
-                const int cy = max((e0 & 0xFFF) - 1, 0);
+                c0r[k] = (oy + wv * 32) - (lat - v.R) * v.dim + v.dim / 2;     // storage column of the word's first column
+                const int cy = max(c0r[k] - 1, 0);
                 const uint32_t* row = v.occ + ((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow;
                 lo[k] = row[cy >> 5];
                 hi[k] = ((cy >> 5) + 1 < v.ow) ? row[(cy >> 5) + 1] : 0u;
@@ -178,21 +194,22 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int q = q0 + k * MBLOCK;
-                if (q >= N * W) continue;
+                if (ww[k] < 0) continue;
+                const int u = uu[k], wv = ww[k];
                 uint32_t bits;
                 if (fast[k]) {
-                    bits = 0;
-                    const int wv = q % W;
-#pragma unroll 8
-                    for (int b = 0; b < 32; ++b) {
-                        const int pcol = (colmap[wv * 32 + b] & 0xFFF) - sh[k];             // 0..95
+                    // 32 consecutive storage columns: a funnel shift of the loaded window, then the defect columns one by one
+                    const int sft = c0r[k] - sh[k];                                          // 0..32
+                    const unsigned long long w01 = ((unsigned long long)hi[k] << 32) | lo[k], w12 = ((unsigned long long)hi2[k] << 32) | hi[k];
+                    bits = sft < 32 ? (uint32_t)(w01 >> sft) : (uint32_t)(w12 >> (sft - 32));
+                    for (uint32_t d = s_def[wv]; d; d &= d - 1) {
+                        const int b = __ffs(d) - 1;
+                        const int pcol = (colmap[wv * 32 + b] & 0xFFF) - sh[k];              // 0..95
                         const uint32_t wsel = pcol < 32 ? lo[k] : pcol < 64 ? hi[k] : hi2[k];
-                        bits |= ((wsel >> (pcol & 31)) & 1u) << b;
+                        bits = (bits & ~(1u << b)) | (((wsel >> (pcol & 31)) & 1u) << b);
                     }
-                } else {                                          // LUT glitch, tile edge or coarser matcher cell: bit by bit
+                } else {                                          // tile edge, unmapped column or coarser matcher cell: bit by bit
                     bits = 0;
-                    const int u = q / W, wv = q % W;
                     for (int du = 0; du < a.ds; ++du) {
                         const uint32_t rb = rowbase[u * a.ds + du];
                         if (rb == 0xFFFFFFFFu) continue;
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                         }
                     }
                 }
-                s.occ[q] = bits;
+                s.occ[u * W + wv] = bits;
             }
         }
         __syncthreads();                                        // colmap memory is the score table again below
@@ -268,6 +285,8 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     const int ntx = 2 * max(ktx, 0) + 1, nty = 2 * max(kty, 0) + 1;
     const int nr = 2 * a.n_coarse_rot + 1;
     const int n_coarse = nr * ntx * nty;
+    for (int i = tid; i < n_coarse; i += MBLOCK) s.sc[i] = 0;           // candidate sums are accumulated with atomics
+    __syncthreads();
 
     MSTAMP(2);
     // Neighbouring translation candidates along y are consecutive bits of one mask row, so one LDS read scores a whole
@@ -277,46 +296,65 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     const int CW = match_crs_words(N);
     const int NC4 = N / M_COARSE;
     // ---- coarse level -------------------------------------------------------------------------------------------
-    for (int item = tid; item < nr * ntx; item += MBLOCK) {
-        const int ir = item / ntx, itx = item % ntx;
-        float sn, cs;
-        __sincosf(gthf + (float)((double)(ir - a.n_coarse_rot) * M_COARSE * a.d0), &sn, &cs);
-        const float tx = fx + (float)((itx - max(ktx, 0)) * M_COARSE);
-        for (int g0 = 0; g0 < nty; g0 += 8) {                       // up to 8 y translations per pass
-            const float ty0 = fy + (float)((g0 - max(kty, 0)) * M_COARSE);
-            int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int bb = 0; bb < n8; bb += 240) {                  // byte-lane sums stay below 256
-                uint32_t accA = 0, accB = 0;
-                const int be = min(n8, bb + 240);
-                for (int b = bb; b < be; b += 4) {
-                    const float4 bx4 = *reinterpret_cast<const float4*>(s.cx8 + b), by4 = *reinterpret_cast<const float4*>(s.cy8 + b);
-                    const float ex[4] = {cs * bx4.x - sn * by4.x + tx, cs * bx4.y - sn * by4.y + tx, cs * bx4.z - sn * by4.z + tx, cs * bx4.w - sn * by4.w + tx};
-                    const float ey[4] = {sn * bx4.x + cs * by4.x + ty0, sn * bx4.y + cs * by4.y + ty0, sn * bx4.z + cs * by4.z + ty0, sn * bx4.w + cs * by4.w + ty0};
-                    uint32_t lo[4], hi[4]; int sh[4];
+    // work item = (rotation, beam slice): a beam is rotated once and looked up for every x translation (a shift by whole
+    // coarse cells) and, through the byte lanes, for 8 y translations per LDS read; slices add their sums with atomics
+    {
+        const int MAXTX = 7;
+        const int NSC = max(1, MBLOCK / nr), G8 = n8 / 4, per = (G8 + NSC - 1) / NSC;
+        for (int item = tid; item < nr * NSC; item += MBLOCK) {
+            const int ir = item / NSC, sl = item % NSC;
+            float sn, cs;
+            __sincosf(gthf + (float)((double)(ir - a.n_coarse_rot) * M_COARSE * a.d0), &sn, &cs);
+            const int g_lo = sl * per, g_hi = min(G8, g_lo + per);
+            for (int g0 = 0; g0 < nty; g0 += 8)                         // up to 8 y translations per pass
+            for (int t0 = 0; t0 < ntx; t0 += MAXTX)                     // up to MAXTX x translations per pass
+            for (int gg = g_lo; gg < g_hi; gg += 60) {                  // byte-lane sums stay below 256
+                const float ty0 = fy + (float)((g0 - max(kty, 0)) * M_COARSE);
+                uint32_t accA[MAXTX], accB[MAXTX];
+#pragma unroll
+                for (int t = 0; t < MAXTX; ++t) { accA[t] = 0; accB[t] = 0; }
+                const int ge = min(g_hi, gg + 60);
+                for (int g = gg; g < ge; ++g) {
+                    const float4 bx4 = *reinterpret_cast<const float4*>(s.cx8 + 4 * g), by4 = *reinterpret_cast<const float4*>(s.cy8 + 4 * g);
+                    const float bxs[4] = {bx4.x, bx4.y, bx4.z, bx4.w}, bys[4] = {by4.x, by4.y, by4.z, by4.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int u = (int)floorf(ex[k]), w0 = (int)floorf(ey[k]);
-                        const int cu = u >> 2, cw0 = w0 >> 2;       // candidate j of this pass looks at coarse column cw0 + j
-                        const bool in = (unsigned)u < (unsigned)N && cw0 >= 0 && cw0 + 7 < NC4;
-                        const int i0 = in ? cu * CW + (cw0 >> 5) : 0;
-                        sh[k] = cw0 & 31;
-                        lo[k] = in ? s.crs[i0] : 0u;
-                        hi[k] = (in && sh[k] > 24 && (cw0 >> 5) + 1 < CW) ? s.crs[i0 + 1] : 0u;
-                    }
+                        const int u0 = (int)floorf(cs * bxs[k] - sn * bys[k] + fx) + (t0 - max(ktx, 0)) * M_COARSE;
+                        const int cw0 = (int)floorf(sn * bxs[k] + cs * bys[k] + ty0) >> 2;   // candidate j looks at coarse column cw0 + j
+                        const bool col_ok = cw0 >= 0 && cw0 + 7 < NC4;
+                        const int sh = cw0 & 31, wi = cw0 >> 5;
+                        const bool two = sh > 24 && wi + 1 < CW;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t bits = ((lo[k] >> sh[k]) | (sh[k] ? hi[k] << (32 - sh[k]) : 0u)) & 0xFFu;
-                        accA += ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
-                        accB += ((bits >> 4) * 0x00204081u) & 0x01010101u;
+                        for (int t = 0; t < MAXTX; ++t) {
+                            const int u = u0 + t * M_COARSE;
+                            const bool in = col_ok && t0 + t < ntx && (unsigned)u < (unsigned)N;
+                            const int i0 = in ? (u >> 2) * CW + wi : 0;
+                            const uint32_t lo = in ? s.crs[i0] : 0u, hi = (in && two) ? s.crs[i0 + 1] : 0u;
+                            const uint32_t bits = ((lo >> sh) | (sh ? hi << (32 - sh) : 0u)) & 0xFFu;
+                            accA[t] += ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+                            accB[t] += ((bits >> 4) * 0x00204081u) & 0x01010101u;
+                        }
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { sum[j] += (accA >> (8 * j)) & 0xFFu; sum[4 + j] += (accB >> (8 * j)) & 0xFFu; }
-            }
+                for (int t = 0; t < MAXTX; ++t) {
+                    if (t0 + t >= ntx) continue;
+                    int* dst = s.sc + (ir * ntx + t0 + t) * nty + g0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (g0 + j < nty) { s.sc[(ir * ntx + itx) * nty + g0 + j] = sum[j]; atomicMax(&s_best, sum[j]); }
+                    for (int j = 0; j < 8; ++j) {
+                        const int val = (int)(((j < 4 ? accA[t] : accB[t]) >> (8 * (j & 3))) & 0xFFu);
+                        if (g0 + j < nty && val) atomicAdd(&dst[j], val);
+                    }
+                }
+            }
         }
+    }
+    __syncthreads();
+    {
+        int mx = INT_MIN;
+        for (int cnd = tid; cnd < n_coarse; cnd += MBLOCK) mx = max(mx, s.sc[cnd]);
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        if ((tid & 63) == 0) atomicMax(&s_best, mx);
     }
     __syncthreads();
     if (tid == 0) s_bestc = INT_MAX;
@@ -464,7 +502,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     __syncthreads();
     MSTAMP(5);
 #ifdef RBPF_STAMPS
-    if (tid == 0) for (int k = 0; k < 6; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
 #endif
     if (tid == 0) {
         double* o = a.out + (size_t)p * 13;

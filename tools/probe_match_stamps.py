@@ -10,7 +10,7 @@ log = synthetic.make_log(16, 1081, period=PERIOD_S)
 r = Runner(P, 1081, 0.05, log)
 for _ in range(5):
     r.step()
-names = ["setup+zero", "field", "dilate+pool", "coarse", "fine", "score+cov"]
+names = ["setup+zero", "field", "dilate+pool", "coarse", "fine", "score+cov", "colmap", "spare"]
 for label in ("adj=0 (own map)", "adj=1 (last scan)"):
     r.e.set_profiling(True)
     n = 0
@@ -24,7 +24,7 @@ for label in ("adj=0 (own map)", "adj=1 (last scan)"):
         r.step()
         if n == 1 and adj != (label.startswith("adj=1")):
             n = 0
-    st = np.array(r.e.counters()["stamps"][:6], dtype=np.float64)
+    c = r.e.counters(); st = np.array(list(c["stamps"]) + [c["cells_gathered"]], dtype=np.float64)
     ms = r.e.kernel_ms("match")
     print(label, "match ms", ms[-2:], "frames", r.frame)
     for nm, v in zip(names, st):
