@@ -83,6 +83,8 @@ struct ProposeArgs {
     double* dbg_w;              // optional [P][K] raw sample weights (tests), or nullptr
 };
 
+static const int WCH = 32;              // samples weighted per pass over the beams
+
 __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
     __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
     __shared__ int s_sum[KMAX];
@@ -145,16 +147,17 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     }
     __syncthreads();
 
-    // ---- weighting: K gathers per beam, samples in chunks of 8 to bound register pressure --------------
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        int acc[8];
+    // ---- weighting: K gathers per beam, samples in chunks of WCH: the samples of a beam end on
+    //      neighbouring cells, so a large chunk re-uses the cache lines while they are still in L1 --------------
+    for (int k0 = 0; k0 < K; k0 += WCH) {
+        int acc[WCH];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0;
+        for (int k = 0; k < WCH; ++k) acc[k] = 0;
         for (int b = tid; b < v.B; b += BLOCK) {
             if (!(v.bflags[b] & BF_WEIGHT)) continue;                 // robot.py:130
             const double x = v.bx[b], y = v.by[b];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < WCH; ++k) {
                 if (k0 + k < K) {
                     double gx = (s_c[k0 + k] * x + (-s_s[k0 + k]) * y) + s_g[k0 + k][0];   // lidar.py:123
                     double gy = (s_s[k0 + k] * x + s_c[k0 + k] * y) + s_g[k0 + k][1];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < WCH; ++k) {
             if (k0 + k < K) {
                 int s = acc[k];
                 for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

@@ -200,11 +200,22 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.occ, (size_t)v.pool_tiles * dim * v.ow);
         HIP_TRY(h, hipMemset(v.occ, 0, (size_t)v.pool_tiles * dim * v.ow * 4));
         ALLOC(h, v.tile_bbox, (size_t)v.pool_tiles * 4); ALLOC(h, v.free_stack, v.pool_tiles); ALLOC(h, v.free_top, 1);
-        double* dtmp; uint8_t* btmp;
-        ALLOC(h, dtmp, (size_t)c.max_beams); v.bx = dtmp;
-        ALLOC(h, dtmp, (size_t)c.max_beams); v.by = dtmp;
-        ALLOC(h, dtmp, (size_t)c.max_beams); v.bscale = dtmp;
-        ALLOC(h, btmp, (size_t)c.max_beams); v.bflags = btmp;
+        {   // the scan block: one device buffer, uploaded with one copy per scan (rbpf_set_scan)
+            const size_t MB = (size_t)c.max_beams, MBP = (MB + 15) & ~(size_t)15;
+            h->scan_bytes = 3 * MBP * 8 + 4 * MBP * 4 + MBP;
+            ALLOC(h, h->d_scan, h->scan_bytes);
+            unsigned char* d = h->d_scan;
+            v.bx = reinterpret_cast<double*>(d); v.by = v.bx + MBP; v.bscale = v.by + MBP;
+            v.msel_x = reinterpret_cast<float*>(d + 3 * MBP * 8); v.msel_y = v.msel_x + MBP; v.asel_x = v.msel_y + MBP; v.asel_y = v.asel_x + MBP;
+            v.bflags = d + 3 * MBP * 8 + 4 * MBP * 4;
+            rbpf_handle::PinnedRing* rings[2] = {&h->ring_scan, &h->ring_last};
+            const size_t bytes[2] = {h->scan_bytes, MB * 16};
+            for (int r = 0; r < 2; ++r) {
+                rings[r]->slot_bytes = (bytes[r] + 255) & ~(size_t)255;
+                HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&rings[r]->base), rings[r]->slot_bytes * rbpf_handle::PinnedRing::N, hipHostMallocDefault));
+                for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) HIP_TRY(h, hipEventCreateWithFlags(&rings[r]->ev[i], hipEventDisableTiming));
+            }
+        }
         ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.n_items, 2);
         ALLOC(h, v.stats, 16); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
@@ -212,8 +223,6 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             const char* mk = getenv("RBPF_MAP_KERNEL");
             v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
         }
-        ALLOC(h, v.msel_x, (size_t)c.max_beams); ALLOC(h, v.msel_y, (size_t)c.max_beams);
-        ALLOC(h, v.asel_x, (size_t)c.max_beams); ALLOC(h, v.asel_y, (size_t)c.max_beams);
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
         if (raycast_lds_bytes(c.max_beams, v.reach) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
         match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
@@ -268,6 +277,10 @@ int rbpf_destroy(rbpf_handle* h) {
     if (h->d_i32) hipFree(h->d_i32);
     if (h->d_jobs) hipFree(h->d_jobs);
     if (h->h_pinned) hipHostFree(h->h_pinned);
+    for (rbpf_handle::PinnedRing* r : {&h->ring_scan, &h->ring_last}) {
+        if (r->base) hipHostFree(r->base);
+        for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
+    }
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) for (int e = 0; e < 2; ++e) for (auto& ev : h->ring[k][e]) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -351,11 +364,15 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
     if (!h || !ranges || !angles) return RBPF_EINVAL;
     if (B < 1 || B > h->cfg.max_beams) return fail(h, RBPF_EINVAL, "n_beams out of range");
     const rbpf_config& c = h->cfg;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));        // the staging buffer may still be in flight
-    double* sx = static_cast<double*>(h->h_pinned);
-    double* sy = sx + B;
-    double* sc = sy + B;
-    uint8_t* fl = reinterpret_cast<uint8_t*>(sc + B);
+    const size_t MBP = ((size_t)c.max_beams + 15) & ~(size_t)15;
+    unsigned char* slot = static_cast<unsigned char*>(h->ring_scan.acquire());
+    double* sx = reinterpret_cast<double*>(slot);
+    double* sy = sx + MBP;
+    double* sc = sy + MBP;
+    float* mx = reinterpret_cast<float*>(slot + 3 * MBP * 8);               // compacted beam lists for the matcher
+    float* my = mx + MBP; float* ax = my + MBP; float* ay = ax + MBP;       // (float32, sensor frame)
+    uint8_t* fl = slot + 3 * MBP * 8 + 4 * MBP * 4;
+    int nm = 0, na = 0;
     for (int i = 0; i < B; ++i) {
         double x = ranges[i] * cos(angles[i]);           // lidar.py:78
         double y = ranges[i] * sin(angles[i]);           // lidar.py:79
@@ -367,26 +384,13 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
         double s = 1.0;
         if (dist > c.max_ray_m) { f |= BF_LONG; s = c.max_ray_m / dist; }             // hybridmap.py:107-108
         sx[i] = x; sy[i] = y; sc[i] = s; fl[i] = f;
+        if (f & BF_MATCH) { mx[nm] = (float)x; my[nm] = (float)y; ++nm; }
+        if (f & BF_MATCH_ADJ) { ax[na] = (float)x; ay[na] = (float)y; ++na; }
     }
     DevView& v = h->v;
-    {   // compacted beam lists for the matcher (float32, sensor frame)
-        float* mx = reinterpret_cast<float*>(fl + ((B + 15) & ~15));
-        float* my = mx + B; float* ax = my + B; float* ay = ax + B;
-        int nm = 0, na = 0;
-        for (int i = 0; i < B; ++i) {
-            if (fl[i] & BF_MATCH) { mx[nm] = (float)sx[i]; my[nm] = (float)sy[i]; ++nm; }
-            if (fl[i] & BF_MATCH_ADJ) { ax[na] = (float)sx[i]; ay[na] = (float)sy[i]; ++na; }
-        }
-        v.n_msel = nm; v.n_asel = na;
-        HIP_TRY(h, hipMemcpyAsync(v.msel_x, mx, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(v.msel_y, my, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(v.asel_x, ax, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(v.asel_y, ay, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    }
-    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.bx), sx, B * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.by), sy, B * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(v.bscale), sc, B * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(v.bflags), fl, B, hipMemcpyHostToDevice, h->stream));
+    v.n_msel = nm; v.n_asel = na;
+    HIP_TRY(h, hipMemcpyAsync(h->d_scan, slot, h->scan_bytes, hipMemcpyHostToDevice, h->stream));   // pinned: no stream drain
+    h->ring_scan.submitted(h->stream);
     v.B = B;
     h->have_scan = true;
     return RBPF_OK;
@@ -464,7 +468,12 @@ static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, 
     DevView& v = h->v;
     if (adj && (!last_scan_xy || n_last < 0 || n_last > h->cfg.max_beams))
         return fail(h, RBPF_EINVAL, "adj = 1 needs last_scan_xy with at most max_beams points");
-    if (adj) HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, last_scan_xy, (size_t)n_last * 16, hipMemcpyHostToDevice, h->stream));
+    if (adj) {
+        void* slot = h->ring_last.acquire();
+        memcpy(slot, last_scan_xy, (size_t)n_last * 16);
+        HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, slot, (size_t)n_last * 16, hipMemcpyHostToDevice, h->stream));
+        h->ring_last.submitted(h->stream);
+    }
     h->prof_begin(3);
     launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
                            h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, h->stream);

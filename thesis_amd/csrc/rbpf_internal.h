@@ -88,6 +88,16 @@ struct rbpf_handle {
     std::vector<void*> allocs;
     // host staging
     void* h_pinned = nullptr; size_t h_pinned_bytes = 0;
+    // pinned staging rings for the per-step uploads (scan block, previous scan): a slot is reused only after the copy
+    // that read it has completed (its event), so uploading never drains the stream
+    struct PinnedRing {
+        static const int N = 4;
+        unsigned char* base = nullptr; size_t slot_bytes = 0; int next = 0; hipEvent_t ev[N] = {}; bool used[N] = {};
+        void* acquire() { if (used[next]) (void)hipEventSynchronize(ev[next]); return base + (size_t)next * slot_bytes; }
+        void submitted(hipStream_t s) { (void)hipEventRecord(ev[next], s); used[next] = true; next = (next + 1) % N; }
+    };
+    PinnedRing ring_scan, ring_last;
+    unsigned char* d_scan = nullptr; size_t scan_bytes = 0;   // device scan block, same layout as a ring_scan slot
     // scratch device buffers for test entries
     double* d_guess = nullptr; double* d_prs = nullptr; double* d_w = nullptr; size_t d_guess_n = 0;
     int mN = 0, mds = 1, mncr = 0; double mmcs = 0, md0 = 0; size_t mlds = 0;
