@@ -90,7 +90,7 @@ class Runner:
         self.frame += 1
 
 
-KERNEL_NAMES = {"raycast": "rbpf::map_update_kernel", "match": "rbpf::match_kernel",
+KERNEL_NAMES = {"raycast": "rbpf::map_update_fan_kernel", "match": "rbpf::match_kernel",
                 "weight": "rbpf::propose_weight_kernel", "resample": "rbpf::resample_copy_kernel"}
 
 
@@ -225,6 +225,7 @@ def main():
                 "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,
                 "achieved_stored_bytes_GBs": ach / 4.0,
                 "kernel_ms_mean": mean_ms, "slow_cells_per_step": c["slow_cells"] / n_upd,
+                "window_fallback_particles_per_step": c["window_fallbacks"] / n_upd,
                 "unique_cells_written_per_particle": W_per_particle,
                 "ray_cells_per_particle": cells_per_particle}
     out = {"metric": "particle-updates/sec (particles x scans/s) @1081 beams", "value": value,

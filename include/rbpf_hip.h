@@ -184,6 +184,7 @@ int  rbpf_set_state(rbpf_handle* h, const double* poses_p3, const double* covs_p
 int  rbpf_get_tile_count(rbpf_handle* h, int32_t particle, int32_t* out_n);
 /* k-th tile of a particle in lattice order: centre (metres) and dim*dim cells, cell[x*dim+y] */
 int  rbpf_get_tile(rbpf_handle* h, int32_t particle, int32_t k, double* centre2, int8_t* cells);
+/* cells must lie in [min_odds_emp, max_odds_occ] / quantum, as every map of the reference does (RBPF_EINVAL) */
 int  rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const int8_t* cells);
 int  rbpf_get_dim(rbpf_handle* h, int32_t* out_dim);
 /* HybridMap.get_odds_at (hybridmap.py:85-93) for n points against particle p's map;

@@ -36,8 +36,8 @@ static const int FB = 1024;                    // threads per particle
 static const int MINI_R = CHUNK - 1;           // cells with Chebyshev distance <= MINI_R from the start cell ...
 static const int MINI_W = 2 * MINI_R + 1;      // ... live in the 16-bit block
 static const int FNB_MAX = 4 * FB;             // flagged cells (two per beam at most)
-static const int FEV = 6144;                   // ordered events
-static const int FMARK = 2048;                 // chunks that met a flagged cell
+static const int FEV = 5120;                   // ordered events
+static const int FMARK = 256;                  // chunks that met a flagged cell more than 32 steps before the ray's end
 static const int FLIST = 256;                  // deep buckets (17..64 events) / membership-scan cells per particle
 static const int MAXLEV = 20;                  // chunks per ray
 static const int BLK = 128;                    // cells per block of the flagged-cell directory
@@ -46,7 +46,7 @@ static const int BLK = 128;                    // cells per block of the flagged
 struct FanGeom {
     int ncell, nblk, fanw, nb, bpad;             // ncell = window capacity in cells (rows * stride of a particle's fan must fit)
     int o_cnt, o_fpre, o_mini, o_rend, o_rinfo, o_perm, o_ux, o_uy, o_gpx, o_gpy, o_bcell, o_floff, o_oldv, o_off,
-        o_lists, o_mark, o_dummy, o_bev;
+        o_lists, o_mark, o_rmask, o_dummy, o_bev;
     int bytes;
     bool ok;
 };
@@ -63,7 +63,7 @@ __host__ __device__ inline FanGeom fan_geom(int B, int reach) {
     int fixed = 0;
     fixed += fan_al16(((MINI_W * MINI_W + 1) / 2) * 4) + fan_al16(g.bpad * 4) + fan_al16(B) + fan_al16(g.bpad * 2);
     fixed += 2 * fan_al16(g.fanw * 2) + 2 * fan_al16(g.fanw) + fan_al16(g.nb * 4) + 2 * fan_al16(g.nb) + fan_al16(((g.nb + 1) / 2) * 4);
-    fixed += fan_al16(2 * FLIST * 2) + FMARK * 2 + 256 + FEV * 2;
+    fixed += fan_al16(2 * FLIST * 2) + FMARK * 4 + g.bpad * 4 + 256 + FEV * 2;
     const int avail = 160 * 1024 - 1024 - fixed - 64;      // 1 KB for the kernel's static LDS
     int ncell = avail > 0 ? (int)(((long long)avail * 64) / 65) & ~(BLK - 1) : 0;
     if (ncell > BLK * FB) ncell = BLK * FB;                // one directory block per thread in the scan
@@ -85,7 +85,8 @@ __host__ __device__ inline FanGeom fan_geom(int B, int reach) {
     g.o_oldv = o;  o += fan_al16(g.nb);
     g.o_off = o;   o += fan_al16(((g.nb + 1) / 2) * 4);
     g.o_lists = o; o += fan_al16(2 * FLIST * 2);
-    g.o_mark = o;  o += FMARK * 2;
+    g.o_mark = o;  o += FMARK * 4;
+    g.o_rmask = o; o += fan_al16(g.bpad * 4);
     g.o_dummy = o; o += 256;
     g.o_bev = o;   o += FEV * 2;
     g.bytes = o;
@@ -96,7 +97,8 @@ __host__ __device__ inline FanGeom fan_geom(int B, int reach) {
 
 bool map_update_fan_available(const DevView& v) {
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);
-    return fan_geom(v.B, v.reach).ok && v.dim % 32 == 0 && v.L * v.L <= 49 && sat <= 64 && v.cc.emp < 0 && v.cc.vmax - v.cc.vmin <= 127;
+    return fan_geom(v.B, v.reach).ok && v.dim % 32 == 0 && v.L * v.L <= 49 && sat <= 64 && v.cc.emp < 0 && v.cc.vmax - v.cc.vmin <= 127 && v.cc.vmin <= 0 && v.cc.vmax >= 0 &&
+           v.cc.vmin >= -127 && (int)sat * -v.cc.emp <= 127 && v.cc.thr >= v.cc.vmin && v.cc.thr < v.cc.vmax;
 }
 
 // atomicAdd(&arr[key], 1) for every lane with valid = true, one LDS atomic per distinct key in the wave (a handful of
@@ -138,7 +140,7 @@ template <> struct Fld<true> {
 template <bool MINI, bool SAT>
 __device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* __restrict__ sink, int c, int dmajc, int dminc,
                                            int D, int dmaj2, int dmin2, int jlo, int jhi, int n, uint32_t sat,
-                                           bool near_ok, bool& hit, uint32_t& guard) {
+                                           bool near_ok, uint32_t& hmask, uint32_t& guard) {
     typedef Fld<MINI> F;
     int j = jlo;
     for (; j + 3 <= jhi; j += 4) {
@@ -174,7 +176,8 @@ __device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* 
             if (!MINI) guard |= h[u] & (h[u] << 1);
         }
         if (any & F::FLAG) {                                               // rare: a cell with ordered events
-            hit = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (h[u] & F::FLAG) hmask |= 1u << (j + u - jlo);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if ((h[u] & F::FLAG) && near_ok && n - 1 - (j + u) == 1) {   // hybridmap.py:139-142: the NEARBY event
@@ -213,7 +216,8 @@ __device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* 
             if (!MINI) guard |= h[u] & (h[u] << 1);
         }
         if (any & F::FLAG) {
-            hit = true;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) if (h[u] & F::FLAG) hmask |= 1u << (j + u - jlo);
 #pragma unroll
             for (int u = 0; u < 3; ++u)
                 if ((h[u] & F::FLAG) && near_ok && n - 1 - (j + u) == 1) {
@@ -246,7 +250,8 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     uint16_t* const off16 = reinterpret_cast<uint16_t*>(smem + G.o_off);
     uint16_t* const bigc = reinterpret_cast<uint16_t*>(smem + G.o_lists);  // [FLIST] ids with 17..64 events: one wave each
     uint16_t* const slowc = bigc + FLIST;
-    uint16_t* const mark = reinterpret_cast<uint16_t*>(smem + G.o_mark);   // [FMARK] walk items that met a flagged cell                                  // [FLIST] more than 64: exact membership scan
+    uint32_t* const mark = reinterpret_cast<uint32_t*>(smem + G.o_mark);   // [FMARK] walk item | steps that met a flagged cell << 16 (early steps only)
+    uint32_t* const rmask = reinterpret_cast<uint32_t*>(smem + G.o_rmask); // [B] bit i: step n - 32 + i of the ray met a flagged cell                                  // [FLIST] more than 64: exact membership scan
     uint32_t* const dummy = reinterpret_cast<uint32_t*>(smem + G.o_dummy); // per-lane sink for skipped adds
     uint16_t* const bev = reinterpret_cast<uint16_t*>(smem + G.o_bev);     // [FEV] (beam << 3) | rank
 
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
         for (int i = tid; i < n16; i += FB) c4[i] = make_uint4(0, 0, 0, 0);
         for (int i = tid; i < (MINI_W * MINI_W + 1) / 2; i += FB) mini[i] = 0;
         if (tid < 64) dummy[tid] = 0;
+        for (int i = tid; i < G.bpad; i += FB) rmask[i] = 0;
     }
     __syncthreads();
     STAMP(7);
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                 const int xl = x0 + min(ex, 0) - fxl, xh = x0 + max(ex, 0) - fxl, yl = y0 + min(ey, 0) - fyl, yh = y0 + max(ey, 0) - fyl;
                 ident = gpx[xl] == gpx[xh] && gpy[yl] == gpy[yh];
             }
-            bool hit = false;
+            uint32_t hit = 0;                                                      // bit u: step jlo + u met a flagged cell
             uint32_t acc = 0;
             if (ident) {
                 const int dxj = r.steep ? smin * m : smaj * jlo, dyj = r.steep ? smaj * jlo : smin * m;   // offset of step jlo
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                         const uint32_t f = (h[u] >> sh[u]) & (2 * fm[u] - 1);
                         if (fm[u] == 0x80u) acc |= f & (f << 1);
                         if (f & fm[u]) {
-                            hit = true;
+                            hit |= 1u << (j4 + u - jlo);
                             if (near_ok && r.n - 1 - (j4 + u) == 1) {
                                 const uint32_t f2 = (atomicAdd(wp[u], 1u << sh[u]) >> sh[u]) & (2 * fm[u] - 1);
                                 if (fm[u] == 0x80u) acc |= f2 & (f2 << 1);
@@ -621,9 +627,15 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                     }
                 }
             }
-            if (hit) {
-                const int pos = atomicAdd(&s_nmark, 1);
-                if (pos < FMARK) mark[pos] = (uint16_t)q; else s_fb = 1;
+            if (hit) {   // the steps that met a flagged cell: a bit per step of the ray's last 32 steps, a list entry for earlier ones
+                const int rel = jlo - (r.n - 32);                                   // bit position of step jlo
+                const uint32_t late = rel >= 0 ? hit << rel : hit >> min(-rel, 31);
+                const uint32_t early = rel >= 0 ? 0u : hit & ((1u << min(-rel, 16)) - 1u);
+                if (late) atomicOr(&rmask[b], late);
+                if (early) {
+                    const int pos = atomicAdd(&s_nmark, 1);
+                    if (pos < FMARK) mark[pos] = (uint32_t)q | (early << 16); else s_fb = 1;
+                }
             }
             if (acc & 0x40u) s_fb = 1;                                               // a field was seen at >= GUARD
         }
@@ -676,28 +688,25 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     }
     BAR_LDS();
     STAMP(3);
-    // ---- re-walk the chunks that met a flagged cell: every such hit becomes an event in its cell's bucket ----
-    const int nmark = UNI(s_nmark);
-    for (int qm = tid; qm < nmark; qm += FB) {
-        const int q = mark[qm];                                                      // item index of the walk: level, ray
-        int k = 0, base = 0, nxt = s_lp[1];
-        for (int kk = 1; kk < MAXLEV; ++kk) if (q >= s_lp[kk]) { k = kk; base = s_lp[kk]; nxt = s_lp[kk + 1]; }
-        const int b = perm[((q - base) & 63) * ((nxt - base) >> 6) + ((q - base) >> 6)];
+    // ---- re-walk the steps that met a flagged cell: every such hit becomes an event in its cell's bucket ----
+    // steps: bit i = step jbase + i of beam b
+    auto emit_events = [&](int b, int jbase, uint32_t steps) {
         const int info = r_info[b];
         int x1, y1;
         unpack_end(r_end[b], x0, y0, x1, y1);
         const Ray r = ray_make(x0, y0, x1, y1);
-        const int jlo = k * CHUNK, jhi = min(r.n - 1, jlo + CHUNK - 1);
+        const int jlo = jbase + __ffs(steps) - 1, jhi = jbase + 31 - __clz(steps);
         const int smaj = r.steep ? r.sy : r.sx, smin = r.steep ? r.sx : r.sy;
         const int m0 = r.steep ? y0 : x0, n0 = r.steep ? x0 : y0;
         const bool occ = info & RI_OCC, near_ok = info & RI_NEAR;
-        int m = k ? ray_minor_at(r, jlo) : 0;
+        int m = jlo ? ray_minor_at(r, jlo) : 0;
         int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;
         for (int j = jlo; j <= jhi; ++j) {
             const int maj = m0 + smaj * j, mnr = n0 + smin * m;
             const int gx = r.steep ? mnr : maj, gy = r.steep ? maj : mnr;
             if (D >= 0) { ++m; D -= 2 * r.dmaj; }
             D += 2 * r.dmin;
+            if (!((steps >> (j - jbase)) & 1u)) continue;
             const int c = ((int)ux[gx - fxl] - Ux0) * stride + ((int)uy[gy - fyl] - Uy0al);
             if (!(cnt8[c] & 0x80u)) continue;
             const int id = cell_id(c);
@@ -711,6 +720,21 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                 if (slot < FEV) bev[slot] = (uint16_t)((b << 3) | EV_NEAR);
             }
         }
+    };
+    for (int b = tid; b < v.B; b += FB) {                                            // the last 32 steps of every ray
+        const uint32_t steps = rmask[b];
+        if (!steps) continue;
+        int x1, y1;
+        unpack_end(r_end[b], x0, y0, x1, y1);
+        emit_events(b, ray_make(x0, y0, x1, y1).n - 32, steps);
+    }
+    const int nmark = UNI(s_nmark);
+    for (int qm = tid; qm < nmark; qm += FB) {                                       // earlier steps (rays that graze a flagged cell)
+        const uint32_t me = mark[qm];
+        const int q = (int)(me & 0xFFFFu);                                           // item index of the walk: level, ray
+        int k = 0, base = 0, nxt = s_lp[1];
+        for (int kk = 1; kk < MAXLEV; ++kk) if (q >= s_lp[kk]) { k = kk; base = s_lp[kk]; nxt = s_lp[kk + 1]; }
+        emit_events(perm[((q - base) & 63) * ((nxt - base) >> 6) + ((q - base) >> 6)], k * CHUNK, me >> 16);
     }
     BAR_LDS();
 
@@ -780,6 +804,10 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     //      The group's word of the tile's occupancy bitmask (cell > threshold, gridmap.py:153) is rebuilt.
     {
         int my_written = 0;
+        const int eabs = -v.cc.emp;
+        const uint32_t kb1 = (uint32_t)(128 + v.cc.vmin) * 0x01010101u;             // byte-wise: (cell ^ 0x80) - kb1 = cell - vmin
+        const uint32_t satb = sat * 0x01010101u, sadd = (128u - sat) * 0x01010101u;
+        const uint32_t oadd = (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u; // bit 7 of (R + oadd) = cell > thr
         const int Ux1 = Ux0 + rows_u - 1, Uy1 = Uy0al + cols_u - 1;
         const int gpt = v.dim >> 5;                                                // 32-cell groups per tile row
         for (int a = Ux0 / v.dim; a <= Ux1 / v.dim; ++a)
@@ -812,28 +840,35 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                     const uint4 q0 = reinterpret_cast<const uint4*>(g_ptr)[0], q1 = reinterpret_cast<const uint4*>(g_ptr)[1];
                     pre[0] = q0.x; pre[1] = q0.y; pre[2] = q0.z; pre[3] = q0.w; pre[4] = q1.x; pre[5] = q1.y; pre[6] = q1.z; pre[7] = q1.w;
                 }
-                uint32_t occ = 0;
+                // Four cells per 32-bit word at a time (bytes never carry into each other: cells lie in [vmin, vmax],
+                // hit counts below 96, sat * |emp| below 128): O = cell - vmin, R = max(O - |emp| * min(n, sat), 0).
+                uint32_t occ = 0, touched = 0;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
-                    uint32_t word = pre[w];
+                    const uint32_t Ob = (pre[w] ^ 0x80808080u) - kb1;                       // cells biased to [0, vmax - vmin]
+                    uint32_t R = Ob;
                     if (n[w]) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const uint32_t f = (n[w] >> (8 * k)) & 0xFFu;
-                            if (!f) continue;
-                            int val;
-                            if (f & 0x80u) val = (int)(f & 0x7Fu) + v.cc.vmin;                 // replayed in phase 3
-                            else val = cell_emp_n((int)(int8_t)((word >> (8 * k)) & 0xFFu), (int)f, v.cc);
-                            word = (word & ~(0xFFu << (8 * k))) | (((uint32_t)val & 0xFFu) << (8 * k));
-                            ++my_written;
-                            by0 = min(by0, col + 4 * w + k); by1 = max(by1, col + 4 * w + k);
+                        const uint32_t nw = n[w], n7 = nw & 0x7F7F7F7Fu;
+                        const uint32_t ge = (n7 + sadd) & 0x80808080u;                      // fields >= sat
+                        const uint32_t gem = ge | (ge - (ge >> 7));
+                        const uint32_t m = (satb & gem) | (n7 & ~gem);                      // min(n, sat)
+                        const uint32_t dec = eabs == 3 ? m + (m << 1) : m * (uint32_t)eabs;
+                        const uint32_t T1 = (Ob | 0x80808080u) - dec;
+                        const uint32_t pos = T1 & 0x80808080u;                              // O - dec >= 0
+                        R = T1 & 0x7F7F7F7Fu & (pos | (pos - (pos >> 7)));
+                        const uint32_t fl = nw & 0x80808080u;
+                        if (fl) {                                                           // replayed cells: the field holds value - vmin
+                            const uint32_t flm = fl | (fl - (fl >> 7));
+                            R = (n7 & flm) | (R & ~flm);
                         }
-                        g_ptr[w] = word;
+                        g_ptr[w] = (R + kb1) ^ 0x80808080u;
+                        const uint32_t nz = ((n7 + 0x7F7F7F7Fu) | nw) & 0x80808080u;        // fields that are not zero
+                        touched |= __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false) << (4 * w);
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        occ |= ((int)(int8_t)((word >> (8 * k)) & 0xFFu) > v.cc.thr ? 1u : 0u) << (4 * w + k);
+                    occ |= __builtin_amdgcn_udot4(((R + oadd) & 0x80808080u) >> 7, 0x08040201u, 0u, false) << (4 * w);   // cell > thr
                 }
+                my_written += __popc(touched);
+                by0 = min(by0, col + __ffs(touched) - 1); by1 = max(by1, col + 31 - __clz(touched));
                 v.occ[((size_t)tile * v.dim + row) * v.ow + (col >> 5)] = occ;
                 bx0 = min(bx0, row); bx1 = max(bx1, row);
             }

@@ -859,6 +859,9 @@ int rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const 
     int a = (int)lround(fa), b = (int)lround(fb);
     if (fabs(fa - a) > 1e-9 || fabs(fb - b) > 1e-9 || abs(a) > v.R || abs(b) > v.R)
         return fail(h, RBPF_EINVAL, "tile centre must lie on the tile lattice inside lattice_radius");
+    // the reference's cells never leave [min_odds_emp, max_odds_occ] (gridmap.py:86-117); the map kernels rely on it
+    for (size_t i = 0, n = (size_t)v.dim * v.dim; i < n; ++i)
+        if (cells[i] < v.cc.vmin || cells[i] > v.cc.vmax) return fail(h, RBPF_EINVAL, "cell value outside [min_odds_emp, max_odds_occ]");
     const size_t LL = (size_t)v.L * v.L, idx = (size_t)(a + v.R) * v.L + (b + v.R);
     int32_t t = tab[idx];
     if (t < 0) {   // pop a tile from the free stack on the host side
