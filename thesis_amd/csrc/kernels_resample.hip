@@ -258,10 +258,24 @@ __device__ __forceinline__ void copy_rows(int8_t* dst, const int8_t* src, int di
     }
 }
 
-// occupancy-bitmask rows x0..x1 of a tile (whole rows: ow words each); src == nullptr zero-fills
-__device__ __forceinline__ void copy_occ_rows(uint32_t* dst, const uint32_t* src, int ow, int x0, int x1, int tid) {
-    const int n = (x1 - x0 + 1) * ow;
-    for (int q = tid; q < n; q += BLOCK) dst[(size_t)x0 * ow + q] = src ? src[(size_t)x0 * ow + q] : 0u;
+// occupancy-bitmask words of rows x0..x1, columns y0..y1 of a tile; src == nullptr zero-fills; eight loads in flight per thread
+__device__ __forceinline__ void copy_occ_rows(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int ow, int x0, int x1,
+                                              int y0, int y1, int tid) {
+    const int wa = y0 >> 5, per_row = (y1 >> 5) - wa + 1;
+    const int n = (x1 - x0 + 1) * per_row;
+    for (int q0 = tid; q0 < n; q0 += 8 * BLOCK) {
+        uint32_t val[8]; size_t off[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = q0 + k * BLOCK;
+            const int qq = q < n ? q : q0;
+            off[k] = (size_t)(x0 + qq / per_row) * ow + wa + qq % per_row;
+            val[k] = src ? src[off[k]] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (q0 + k * BLOCK < n) dst[off[k]] = val[k];
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
             int x0 = min(sb[0], db[0]), x1 = max(sb[1], db[1]), y0 = min(sb[2], db[2]), y1 = max(sb[3], db[3]);
             if (x0 <= x1 && y0 <= y1) {
                 copy_rows(v.pool + (size_t)td * cells, v.pool + (size_t)ts * cells, v.dim, x0, x1, y0, y1, tid);
-                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, v.occ + (size_t)ts * v.dim * v.ow, v.ow, x0, x1, tid);
+                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, v.occ + (size_t)ts * v.dim * v.ow, v.ow, x0, x1, y0, y1, tid);
                 if (tid == 0) {
                     const int ya = y0 & ~15, yb = min((y1 | 15) + 1, v.dim);
                     atomicAdd(&v.stats[ST_COPY_BYTES], 2ull * (unsigned long long)(x1 - x0 + 1) * (yb - ya));
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
             if (db[0] <= db[1] && db[2] <= db[3])
             {
                 copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
-                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], tid);
+                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
             }
             if (tid == 0) {
                 v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1;
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJo
         for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
         if (db[0] <= db[1] && db[2] <= db[3]) {
             copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
-            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], tid);
+            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
         }
         if (tid == 0) {
             v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1; v.tile_bbox[4 * td + 2] = INT_MAX; v.tile_bbox[4 * td + 3] = -1;
@@ -457,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJo
         for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
         if (db[0] <= db[1] && db[2] <= db[3]) {
             copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
-            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], tid);
+            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
         }
         __syncthreads();
     }

@@ -1,6 +1,7 @@
 """Short run of the 10 240-particle workload for rocprofv3 --pmc passes (developer tool)."""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import Runner, PERIOD_S
 from thesis_amd.datasets import synthetic
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 10240
