@@ -181,6 +181,10 @@ int  rbpf_get_covs(rbpf_handle* h, double* out_p9);
 int  rbpf_get_weights(rbpf_handle* h, double* out_p);
 int  rbpf_set_state(rbpf_handle* h, const double* poses_p3, const double* covs_p9,
                     const double* weights_p);             /* any pointer may be NULL           */
+/* position of the two internal random streams (sample draws: one per scan update; resample uniforms), for checkpoints
+   that continue a run bit-identically; replaces the `np.random` state the reference pickles (main.py:183-210) */
+int  rbpf_get_rng_state(rbpf_handle* h, uint64_t* scan_updates, uint64_t* resample_draws);
+int  rbpf_set_rng_state(rbpf_handle* h, uint64_t scan_updates, uint64_t resample_draws);
 int  rbpf_get_tile_count(rbpf_handle* h, int32_t particle, int32_t* out_n);
 /* k-th tile of a particle in lattice order: centre (metres) and dim*dim cells, cell[x*dim+y] */
 int  rbpf_get_tile(rbpf_handle* h, int32_t particle, int32_t k, double* centre2, int8_t* cells);

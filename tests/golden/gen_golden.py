@@ -13,6 +13,7 @@ Vector sets:
   G4 get_odds_at                G5 _generate_sample_weight G6 Robot.map_update
   G7 Robot.imu_update           G8 main.resample           G9 get_scan_match inputs
   G10 debug.mat (data file: a captured matchScanCustom argument tuple)
+  G11 dataset adapters (what the Default* / Intel* loaders hand to main.py)
 """
 import contextlib
 import io
@@ -442,8 +443,28 @@ def g10():
          rng=d["rng"].astype(np.float64).ravel())
 
 
+def g11():
+    """Dataset adapters: what DefaultLidarData / DefaultIMUData / IntelLidarData / IntelIMUData
+    hand to main.py, sampled (first/last records, lengths, sums) so that the build's own loaders can be checked."""
+    import DefaultLidarData as ref_default_lidar
+    out = {}
+    t, sc, ang = quiet(ref_default_lidar.DefaultLidarData().load_and_format)
+    out["dl_n"] = np.array(sc.shape); out["dl_times_head"] = np.asarray(t[:5], dtype=np.float64); out["dl_times_tail"] = np.asarray(t[-5:], dtype=np.float64)
+    out["dl_scans_head"] = np.asarray(sc[:3], dtype=np.float64); out["dl_scan_sum"] = np.asarray(sc, dtype=np.float64).sum(axis=1)[:50]
+    out["dl_angles"] = np.asarray(ang, dtype=np.float64)
+    d, ti = quiet(ref_default_imu.DefaultIMUData().load_and_format)
+    out["di_n"] = np.array(d.shape); out["di_head"] = np.asarray(d[:20], dtype=np.float64); out["di_tail"] = np.asarray(d[-5:], dtype=np.float64)
+    out["di_times_head"] = np.asarray(ti[:20], dtype=np.float64); out["di_times_tail"] = np.asarray(ti[-5:], dtype=np.float64)
+    t, sc, ang = quiet(ref_intel_lidar.IntelLidarData().load_and_format)
+    out["il_n"] = np.array(np.asarray(sc).shape); out["il_times_head"] = np.asarray(t[:5], dtype=np.float64)
+    out["il_scan_sum"] = np.asarray(sc, dtype=np.float64).sum(axis=1)[:50]
+    d, ti = quiet(ref_intel_imu.IntelIMUData().load_and_format)
+    out["ii_n"] = np.array(np.asarray(d).shape); out["ii_head"] = np.asarray(d[:10], dtype=np.float64); out["ii_times_head"] = np.asarray(ti[:10], dtype=np.float64)
+    save("G11_dataset_adapters", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g69", "g7", "g8", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g69", "g7", "g8", "g10", "g11"]
     if "g1" in which: g1()
     if "g2" in which: g2()
     if "g345" in which: g3_g4_g5()
@@ -451,3 +472,4 @@ if __name__ == "__main__":
     if "g7" in which: g7()
     if "g8" in which: g8()
     if "g10" in which: g10()
+    if "g11" in which: g11()

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "rbpf_get_covs": (C.c_int, [_H, _D]),
     "rbpf_get_weights": (C.c_int, [_H, _D]),
     "rbpf_set_state": (C.c_int, [_H, _D, _D, _D]),
+    "rbpf_get_rng_state": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rbpf_set_rng_state": (C.c_int, [_H, C.c_uint64, C.c_uint64]),
     "rbpf_get_tile_count": (C.c_int, [_H, C.c_int32, _I]),
     "rbpf_get_tile": (C.c_int, [_H, C.c_int32, C.c_int32, _D, _B]),
     "rbpf_set_tile": (C.c_int, [_H, C.c_int32, C.c_double, C.c_double, _B]),

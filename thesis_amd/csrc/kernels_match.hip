@@ -263,15 +263,26 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         s.dil[q] = acc;
     }
     __syncthreads();
-    for (int q = tid; q < N * W; q += MBLOCK) {
-        uint32_t d = s.dil[q];
-        if (!d) continue;
-        const int u = q / W, wv = q % W;
-        for (int k = 0; k < 32 / M_COARSE; ++k)
-            if ((d >> (k * M_COARSE)) & 0xFu) {
-                int cw = (wv * 32) / M_COARSE + k, cu = u / M_COARSE;
-                atomicOr(&s.crs[cu * match_crs_words(N) + (cw >> 5)], 1u << (cw & 31));
+    // one coarse word (32 coarse columns = 128 field columns) per thread: OR of its four field rows, then every
+    // 4-bit group of the four words collapses into one bit
+    for (int q = tid; q < (N / M_COARSE) * match_crs_words(N); q += MBLOCK) {
+        const int cu = q / match_crs_words(N), cwv = q % match_crs_words(N);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int wv = 4 * cwv + k;
+            uint32_t d = 0;
+            if (wv < W) {
+#pragma unroll
+                for (int r = 0; r < M_COARSE; ++r) d |= s.dil[(cu * M_COARSE + r) * W + wv];
             }
+            d |= d >> 1; d |= d >> 2; d &= 0x11111111u;                  // bit 4j = any of bits 4j .. 4j+3
+            d = (d | (d >> 3)) & 0x03030303u;                            // two bits per byte
+            d = (d | (d >> 6)) & 0x000F000Fu;                            // four bits per half
+            d = (d | (d >> 12)) & 0xFFu;                                 // eight bits
+            out |= d << (8 * k);
+        }
+        s.crs[q] = out;
     }
     __syncthreads();
 

@@ -817,6 +817,18 @@ static int fetch_tab(rbpf_handle* h, int32_t particle, std::vector<int32_t>& tab
     return RBPF_OK;
 }
 
+int rbpf_get_rng_state(rbpf_handle* h, uint64_t* scan_updates, uint64_t* resample_draws) {
+    if (!h || !scan_updates || !resample_draws) return RBPF_EINVAL;
+    *scan_updates = h->scan_updates; *resample_draws = h->resample_draws;
+    return RBPF_OK;
+}
+
+int rbpf_set_rng_state(rbpf_handle* h, uint64_t scan_updates, uint64_t resample_draws) {
+    if (!h) return RBPF_EINVAL;
+    h->scan_updates = scan_updates; h->resample_draws = resample_draws;
+    return RBPF_OK;
+}
+
 int rbpf_get_tile_count(rbpf_handle* h, int32_t particle, int32_t* out_n) {
     if (!h || !out_n) return RBPF_EINVAL;
     std::vector<int32_t> tab;

@@ -212,6 +212,53 @@ class ParticleEngine:
         self._check(self._lib.rbpf_set_tile(self._h, particle, float(centre[0]), float(centre[1]),
                                             cells.ctypes.data_as(C.POINTER(C.c_int8))))
 
+    # -- checkpoint (a portable replacement of the reference's shelve pickles, main.py:183-210) ----
+    CHECKPOINT_VERSION = 1
+
+    def save_checkpoint(self, path: str):
+        """Everything needed to continue the run bit-identically, as one compressed .npz: configuration, particle
+        state, the position of the random streams and every tile (cropped to its non-zero box)."""
+        import json
+        su, rd = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rbpf_get_rng_state(self._h, C.byref(su), C.byref(rd)))
+        owner, centre, box, chunks = [], [], [], []
+        for p in range(self.P):
+            for c, cells in self.tiles(p):
+                xs, ys = np.nonzero(cells)
+                b = (0, 0, 0, 0) if len(xs) == 0 else (int(xs.min()), int(xs.max()) + 1, int(ys.min()), int(ys.max()) + 1)
+                owner.append(p); centre.append(c); box.append(b)
+                chunks.append(cells[b[0]:b[1], b[2]:b[3]].ravel())
+        cfg = {k: (list(getattr(self.cfg, k)) if k == "vel_noise" else getattr(self.cfg, k)) for k, _ in self.cfg._fields_}
+        np.savez_compressed(path, version=np.array(self.CHECKPOINT_VERSION), config=np.array(json.dumps(cfg)),
+                            poses=self.poses(), covs=self.covs(), weights=self.weights(),
+                            rng_state=np.array([su.value, rd.value], dtype=np.uint64),
+                            tile_owner=np.array(owner, dtype=np.int32), tile_centre=np.array(centre, dtype=np.float64).reshape(-1, 2),
+                            tile_box=np.array(box, dtype=np.int32).reshape(-1, 4),
+                            tile_cells=np.concatenate(chunks) if chunks else np.empty(0, dtype=np.int8))
+
+    @classmethod
+    def from_checkpoint(cls, path: str, device: int = 0) -> "ParticleEngine":
+        import json
+        with np.load(path, allow_pickle=False) as d:
+            if int(d["version"]) != cls.CHECKPOINT_VERSION:
+                raise ValueError("unknown checkpoint version")
+            cfg = json.loads(str(d["config"]))
+            skip = {"n_particles", "n_samples", "max_beams", "cell_size", "tile_len_m", "lattice_radius", "pool_tiles", "device", "seed", "reserved0"}
+            over = {k: (tuple(v) if k == "vel_noise" else v) for k, v in cfg.items() if k not in skip}
+            e = cls(cfg["n_particles"], n_samples=cfg["n_samples"], max_beams=cfg["max_beams"], cell_size=cfg["cell_size"],
+                    tile_len_m=cfg["tile_len_m"], lattice_radius=cfg["lattice_radius"], pool_tiles=cfg["pool_tiles"],
+                    device=device, seed=cfg["seed"], **over)
+            e.set_state(d["poses"], d["covs"], d["weights"])
+            e._check(e._lib.rbpf_set_rng_state(e._h, int(d["rng_state"][0]), int(d["rng_state"][1])))
+            off = 0
+            for p, c, b in zip(d["tile_owner"], d["tile_centre"], d["tile_box"]):
+                n = int((b[1] - b[0]) * (b[3] - b[2]))
+                cells = np.zeros((e.dim, e.dim), dtype=np.int8)
+                cells[b[0]:b[1], b[2]:b[3]] = d["tile_cells"][off:off + n].reshape(b[1] - b[0], b[3] - b[2])
+                off += n
+                e.set_tile(int(p), c, cells)
+        return e
+
     def get_odds_at(self, particle: int, xy) -> Tuple[np.ndarray, np.ndarray]:
         pts = _f64(xy).reshape(-1, 2)
         vals = np.empty(len(pts))
