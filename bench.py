@@ -78,12 +78,15 @@ class Runner:
         e.imu_update("velocity", self.odo[k], PERIOD_S * 1e4)                 # main.py:139-145
         e.set_scan(self.ranges[k + 1], self.angles)
         adj = not (k % 5 < 2)                                                 # main.py:156-159
-        e.scan_update(adj=adj, last_scan_xy=self.last_scan_xy if adj else None)
         u = float(self.urng.random())
         if self.shard is None:
+            e.scan_update(adj=adj, last_scan_xy=self.last_scan_xy if adj else None)
             e.resample_async(u)                                               # main.py:160
-        else:
-            self.shard.resample(u)
+        else:   # sharded: the global resample starts as soon as the weights exist and overlaps the map update
+            e.scan_update_begin(adj=adj, last_scan_xy=self.last_scan_xy if adj else None)
+            self.shard.resample_begin(u)
+            e.scan_update_end()
+            self.shard.resample_finish()
         if k % 5 == 0:                                                        # main.py:167
             pose0 = e.poses()[0] if self.shard is None else self.shard.pose_of_particle0()
             self._refresh_last_scan(k + 1, pose0)
@@ -193,6 +196,8 @@ def main():
         elapsed = float(t.item())
         moved = torch.tensor([float(shard.stats["moved"]), float(shard.stats["bytes_sent"])], dtype=torch.float64, device="cuda")
         dist.all_reduce(moved)
+    if run.shard is not None and run.shard.timing is not None:
+        print("shard timing (host s over the run):", {k: round(v, 4) for k, v in run.shard.timing.items()}, file=sys.stderr)
     if rank != 0:
         run.e.close()
         if dist is not None:

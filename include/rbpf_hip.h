@@ -136,6 +136,12 @@ int  rbpf_map_update(rbpf_handle* h, const double* poses);
  *                  (replaces np.random.multivariate_normal, robot.py:81)                       */
 int  rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
                       const double* match_override, const double* guesses);
+/* The same in two halves, for a driver that wants the weights as early as possible (multi-GPU resampling):
+ * _begin = scan matcher, proposal, weighting, moments (robot.py:62-114): the weights are final here unless a particle
+ * took the NaN-covariance branch; _end = the map update at the new mean pose and that branch (robot.py:115, 73-78). */
+int  rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
+                            const double* match_override, const double* guesses);
+int  rbpf_scan_update_end(rbpf_handle* h);
 
 /* ---- a6/a7: scan matcher, stateless twin of the engine seam (hybridmap.py:244-251) ------------ */
 int  rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const double* ref_xy,
@@ -156,12 +162,29 @@ int  rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resa
  * Philox proposal streams are keyed by it, so results do not depend on which rank holds a particle. */
 int  rbpf_set_global_ids(rbpf_handle* h, const int32_t* ids_p);
 /* zero a device vector of n_global doubles and scatter the local weights into it at the global ids, so that
- * an all-reduce(sum) yields the full weight vector on every rank ...                                       */
+ * an all-reduce(sum) yields the full weight vector on every rank.  Stream-ordered on the handle's stream, no host
+ * synchronisation: run the collective on the same stream (rbpf_set_stream with the communicator's stream, e.g.
+ * torch's current stream) or call rbpf_synchronize() first ...                                                 */
 int  rbpf_export_weights(rbpf_handle* h, void* d_global_weights, int32_t n_global);
 /* ... then compute the global systematic-resampling ancestors from it (main.py:46-67), identically on every
  * rank; idx_out[n_global] on the host. */
 int  rbpf_resample_indices_global(rbpf_handle* h, const void* d_global_weights, int32_t n_global,
                                   double u, int32_t* idx_out, int32_t* did_resample);
+/* The early variants, for overlapping the global resample with rbpf_scan_update_end.  Queue, between
+ * rbpf_scan_update_begin and rbpf_scan_update_end and on `stream` (the handle's own stream, or another one: the calls
+ * wait for the weighting kernel through an event):
+ *   rbpf_export_weights_early            the vector has n_global + 1 elements; the last one is 1 on a rank with a
+ *                                        particle on the NaN-covariance branch (robot.py:73-78)
+ *   (the caller's all-reduce(sum) on that stream)
+ *   rbpf_resample_indices_global_early   ancestors + read-back into pinned memory; returns at once
+ * then rbpf_scan_update_end, and finally
+ *   rbpf_resample_indices_global_wait    waits for the read-back only (an event), not for the map update queued
+ *                                        behind it.  *nan_branch_ranks != 0: weights of NaN-branch particles change in
+ *                                        rbpf_scan_update_end - discard the result and use the late calls above. */
+int  rbpf_export_weights_early(rbpf_handle* h, void* d_global_weights_n_plus_1, int32_t n_global, void* stream);
+int  rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global_weights_n_plus_1, int32_t n_global, double u,
+                                        void* stream);
+int  rbpf_resample_indices_global_wait(rbpf_handle* h, int32_t* idx_out, int32_t* did_resample, double* nan_branch_ranks);
 /* serialise n local particles (state + the written boxes of their tiles + occupancy masks) into d_buf;
  * meta_out[n * rbpf_pack_meta_width()] describes the layout for the receiver (host ints) */
 int32_t rbpf_pack_meta_width(rbpf_handle* h);

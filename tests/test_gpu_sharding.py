@@ -92,3 +92,80 @@ def test_two_ranks_on_one_gpu_equal_one_engine():
                 assert np.array_equal(ref[c], tiles_r[i][c]), (rank, i, g, c)
     one.close()
     assert moved >= 0
+
+
+class _OneRankDist:
+    """torch.distributed stand-in for a single rank: the collectives are identities, the backend reads as RCCL so that
+    the device path (and the early, overlapped resample) is the one under test."""
+    class ReduceOp:
+        MAX = "max"
+
+    def get_backend(self):
+        return "nccl"
+
+    def all_reduce(self, t, op=None):
+        return None
+
+    def broadcast(self, t, src=0):
+        return None
+
+    def all_to_all_single(self, recv, send, in_splits, out_splits):
+        recv.copy_(send)
+
+
+def _early_vs_plain(nan_particle, q):
+    """scan_update_begin -> resample_begin -> scan_update_end -> resample_finish (weights exported, all-reduced and
+    turned into ancestors on a side stream while the map update runs) gives exactly the state of scan_update +
+    resample on a plain engine; with a particle on the NaN-covariance branch (robot.py:73-78) the early result is
+    discarded and the late path runs."""
+    import torch
+    torch.cuda.init()                      # torch's device context first, as under torchrun (bench.py)
+    from thesis_amd import engine as eng, sharding
+    from thesis_amd.datasets import synthetic
+    P, B = 48, 1081
+    ang, ranges, odo, _ = synthetic.make_log(5, B, period=0.7)
+    a = eng.ParticleEngine(P, max_beams=B, pool_tiles=4 * P, seed=11)
+    b = eng.ParticleEngine(P, max_beams=B, pool_tiles=4 * P, seed=11)
+    rs = sharding.ShardedResampler(0, 1, P, device=0, dist=_OneRankDist())
+    rs.attach(a)
+    for e in (a, b):
+        e.set_scan(ranges[0], ang)
+        e.map_update(np.zeros((P, 3)))
+    urng = np.random.Generator(np.random.PCG64(3))
+    for k in range(4):
+        u = float(urng.random())
+        mo = None
+        if nan_particle and k == 2:          # the matcher's failure signal for one particle: NaN covariance, score 0
+            mo = np.zeros((P, 13)); mo[:, :3] = [0.35 * (k + 1), 0.0, 0.0]; mo[:, 3] = mo[:, 7] = 1e-4; mo[:, 11] = 1e-5; mo[:, 12] = 100.0
+            mo[5, 3:12] = np.nan; mo[5, 12] = 0.0
+        for e in (a, b):
+            e.imu_update("velocity", odo[k], 7000.0)
+            e.set_scan(ranges[k + 1], ang)
+        a.scan_update_begin(adj=False, match_override=mo)
+        rs.resample_begin(u)
+        a.scan_update_end()
+        did_a, idx_a = rs.resample_finish()
+        b.scan_update(adj=False, match_override=mo)
+        did_b, idx_b = b.resample(u)
+        assert did_a == did_b
+        if did_a:
+            assert np.array_equal(idx_a, idx_b)
+    assert rs.stats.get("late", 0) == (1 if nan_particle else 0)
+    assert np.array_equal(a.poses(), b.poses()) and np.array_equal(a.weights(), b.weights()) and np.array_equal(a.covs(), b.covs())
+    for p in (0, 5, P - 1):
+        for (ca, ta), (cb, tb) in zip(a.tiles(p), b.tiles(p)):
+            assert ca == cb and np.array_equal(ta, tb)
+    a.close(); b.close()
+    q.put("ok")
+
+
+@pytest.mark.parametrize("nan_particle", [False, True])
+def test_early_overlapped_resample_equals_the_plain_engine(nan_particle):
+    """Runs in a fresh process: torch's device context is created there, next to the engine's."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_early_vs_plain, args=(nan_particle, q))
+    pr.start()
+    pr.join(300)
+    assert pr.exitcode == 0 and q.get(timeout=5) == "ok"

@@ -171,3 +171,53 @@ def test_sharded_resample_gloo_matches_single_process(world, p_local):
     assert seen.all()
     np.testing.assert_array_equal(got_s, states)
     np.testing.assert_array_equal(got_t, tags)
+
+
+def _plan_reference(idx, owner, local_of, world, p_local):
+    """The migration rule written out with explicit loops (the documented rule of plan_migration)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    n = len(idx)
+    src_rank = owner[idx]
+    dest = np.full(n, -1, dtype=np.int32)
+    counts, surplus = np.zeros(world, dtype=np.int64), []
+    for r in range(world):
+        js = np.nonzero(src_rank == r)[0]
+        dest[js[:p_local]] = r
+        counts[r] = len(js[:p_local])
+        surplus.append(js[p_local:])
+    pool, k = np.concatenate(surplus), 0
+    for d in range(world):
+        need = int(p_local - counts[d])
+        dest[pool[k:k + need]] = d
+        k += need
+    new_gid, new_src, send = [], [], [[None] * world for _ in range(world)]
+    for r in range(world):
+        js = np.nonzero(dest == r)[0]
+        kept = js[src_rank[js] == r]
+        anc = local_of[idx[kept]]
+        o = np.lexsort((kept, anc))
+        arr = js[src_rank[js] != r]
+        arr = arr[np.lexsort((arr, src_rank[arr]))]
+        new_gid.append(np.concatenate([kept[o], arr])); new_src.append(np.concatenate([anc[o], np.full(len(arr), -1)]))
+        for d in range(world):
+            send[r][d] = local_of[idx[np.nonzero((src_rank == r) & (dest == d) & (r != d))[0]]]
+    return dest, new_gid, new_src, send
+
+
+@pytest.mark.parametrize("world,p_local,seed", [(2, 8, 0), (4, 16, 1), (8, 64, 2), (8, 1024, 3), (3, 5, 4)])
+def test_plan_migration_matches_the_written_out_rule(world, p_local, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = world * p_local
+    perm = rng.permutation(n)                                    # a scrambled ownership, as after earlier resamples
+    owner = (perm // p_local).astype(np.int32)
+    local_of = (perm % p_local).astype(np.int32)
+    for trial in range(4):
+        w = rng.random(n) ** (1 + 3 * trial)
+        idx = np.sort(rng.choice(n, size=n, p=w / w.sum()))      # non-decreasing ancestors, like systematic resampling
+        plan = plan_migration(idx, owner, local_of, world, p_local)
+        dest, gid, src, send = _plan_reference(idx, owner, local_of, world, p_local)
+        assert np.array_equal(plan.dest, dest) and plan.n_move == int((dest != owner[idx]).sum())
+        for r in range(world):
+            assert np.array_equal(plan.new_gid[r], gid[r]) and np.array_equal(plan.new_src[r], src[r])
+            for d in range(world):
+                assert np.array_equal(plan.send[r][d], send[r][d])

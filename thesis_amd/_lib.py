@@ -61,11 +61,16 @@ PROTOTYPES = {
     "rbpf_weight_samples": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
     "rbpf_map_update": (C.c_int, [_H, _D]),
     "rbpf_scan_update": (C.c_int, [_H, C.c_int32, _D, C.c_int32, _D, _D]),
+    "rbpf_scan_update_begin": (C.c_int, [_H, C.c_int32, _D, C.c_int32, _D, _D]),
+    "rbpf_scan_update_end": (C.c_int, [_H]),
     "rbpf_match_scan": (C.c_int, [_H, _D, C.c_int32, _D, C.c_int32, _D, C.c_int32, _D, _D, _D, _D]),
     "rbpf_match_inputs": (C.c_int, [_H, C.c_int32, _D, _D, _I, _D, _I, C.c_int32]),
     "rbpf_resample": (C.c_int, [_H, C.c_double, _I, _I]),
     "rbpf_export_weights": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "rbpf_resample_indices_global": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_double, _I, _I]),
+    "rbpf_export_weights_early": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rbpf_resample_indices_global_early": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "rbpf_resample_indices_global_wait": (C.c_int, [_H, _I, _I, _D]),
     "rbpf_apply_resample_local": (C.c_int, [_H, _I, _I]),
     "rbpf_set_global_ids": (C.c_int, [_H, _I]),
     "rbpf_pack_meta_width": (C.c_int32, [_H]),

@@ -359,9 +359,12 @@ __global__ void resample_release_kernel(DevView v, const int32_t* pending, int32
 // ---- multi-GPU pieces -------------------------------------------------------------------------------------------
 // scatter the local weights to their global particle ids (the caller all-reduces the vector over RCCL)
 __global__ void export_weights_kernel(int P, const double* __restrict__ w, const int32_t* __restrict__ gid,
-                                      double* __restrict__ out, int n_global) {
+                                      double* __restrict__ out, int n_global, const uint8_t* __restrict__ bad) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < P && gid[p] >= 0 && gid[p] < n_global) out[gid[p]] = w[p];
+    // early export: out[n_global] counts (after the all-reduce) the ranks with a particle on the NaN-covariance branch,
+    // whose weight still changes after the map update (robot.py:73-78)
+    if (p < P && bad && bad[p]) out[n_global] = 1.0;
 }
 
 // T[i] = number of new local particles whose source is an old local particle <= i (sources sorted ascending, -1 last)
@@ -490,9 +493,9 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJo
     if (tid == 0) { v.tile_bbox[4 * td + 0] = j.x0; v.tile_bbox[4 * td + 1] = j.x1; v.tile_bbox[4 * td + 2] = j.ya; v.tile_bbox[4 * td + 3] = j.yb - 1; }
 }
 
-void launch_export_weights(const DevView& v, double* d_out, int n_global, hipStream_t s) {
-    (void)hipMemsetAsync(d_out, 0, (size_t)n_global * 8, s);
-    hipLaunchKernelGGL(export_weights_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, v.P, v.weight, v.global_id, d_out, n_global);
+void launch_export_weights(const DevView& v, double* d_out, int n_global, const uint8_t* d_bad, hipStream_t s) {
+    (void)hipMemsetAsync(d_out, 0, (size_t)(n_global + (d_bad ? 1 : 0)) * 8, s);
+    hipLaunchKernelGGL(export_weights_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, v.P, v.weight, v.global_id, d_out, n_global, d_bad);
 }
 void launch_sources_to_T(int P, const int32_t* d_idx, int32_t* d_T, int32_t* d_did, hipStream_t s) {
     hipLaunchKernelGGL(sources_to_T_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, P, d_idx, d_T, d_did);

@@ -208,9 +208,9 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             v.bx = reinterpret_cast<double*>(d); v.by = v.bx + MBP; v.bscale = v.by + MBP;
             v.msel_x = reinterpret_cast<float*>(d + 3 * MBP * 8); v.msel_y = v.msel_x + MBP; v.asel_x = v.msel_y + MBP; v.asel_y = v.asel_x + MBP;
             v.bflags = d + 3 * MBP * 8 + 4 * MBP * 4;
-            rbpf_handle::PinnedRing* rings[2] = {&h->ring_scan, &h->ring_last};
-            const size_t bytes[2] = {h->scan_bytes, MB * 16};
-            for (int r = 0; r < 2; ++r) {
+            rbpf_handle::PinnedRing* rings[3] = {&h->ring_scan, &h->ring_last, &h->ring_idx};
+            const size_t bytes[3] = {h->scan_bytes, MB * 16, (size_t)P * 8};
+            for (int r = 0; r < 3; ++r) {
                 rings[r]->slot_bytes = (bytes[r] + 255) & ~(size_t)255;
                 HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&rings[r]->base), rings[r]->slot_bytes * rbpf_handle::PinnedRing::N, hipHostMallocDefault));
                 for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) HIP_TRY(h, hipEventCreateWithFlags(&rings[r]->ev[i], hipEventDisableTiming));
@@ -219,6 +219,10 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.n_items, 2);
         ALLOC(h, v.stats, 16); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
+        ALLOC(h, h->d_did_early, 1);
+        HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_early, hipEventDisableTiming));
         {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle (tests, comparisons)
             const char* mk = getenv("RBPF_MAP_KERNEL");
             v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
@@ -267,7 +271,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
 
 int rbpf_destroy(rbpf_handle* h) {
     if (!h) return RBPF_OK;
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);              // nullptr = the default stream
     for (void* p : h->allocs) hipFree(p);
     if (h->d_guess) hipFree(h->d_guess);
     if (h->d_prs) hipFree(h->d_prs);
@@ -277,7 +281,10 @@ int rbpf_destroy(rbpf_handle* h) {
     if (h->d_i32) hipFree(h->d_i32);
     if (h->d_jobs) hipFree(h->d_jobs);
     if (h->h_pinned) hipHostFree(h->h_pinned);
-    for (rbpf_handle::PinnedRing* r : {&h->ring_scan, &h->ring_last}) {
+    if (h->ev_weights) hipEventDestroy(h->ev_weights);
+    if (h->ev_early) hipEventDestroy(h->ev_early);
+    if (h->h_early) hipHostFree(h->h_early);
+    for (rbpf_handle::PinnedRing* r : {&h->ring_scan, &h->ring_last, &h->ring_idx}) {
         if (r->base) hipHostFree(r->base);
         for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     }
@@ -291,7 +298,7 @@ const char* rbpf_last_error(const rbpf_handle* h) { return h ? h->err.c_str() : 
 
 int rbpf_set_stream(rbpf_handle* h, void* s) {
     if (!h) return RBPF_EINVAL;
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);              // nullptr = the default stream
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     h->own_stream = false;
     h->stream = static_cast<hipStream_t>(s);
@@ -485,6 +492,14 @@ static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, 
 // ---- Robot.map_update for every particle (robot.py:59-115) -------------------------------------------------
 int rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
                      const double* match_override, const double* guesses) {
+    int rc = rbpf_scan_update_begin(h, adj, last_scan_xy, n_last, match_override, guesses);
+    return rc ? rc : rbpf_scan_update_end(h);
+}
+
+// first half: scan matcher, proposal, weighting, moments (robot.py:62-114); the weights are final here unless a
+// particle took the NaN branch
+int rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
+                           const double* match_override, const double* guesses) {
     if (!h) return RBPF_EINVAL;
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     DevView& v = h->v;
@@ -503,6 +518,19 @@ int rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, in
     h->prof_begin(1);
     launch_propose_weight(v, h->d_match, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
     h->prof_end(1);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev_weights, h->stream));
+    h->ev_weights_valid = true;
+    h->scan_begun = true;
+    return RBPF_OK;
+}
+
+// second half: the map update at the new mean pose and the NaN-covariance branch (robot.py:115, 73-78)
+int rbpf_scan_update_end(rbpf_handle* h) {
+    if (!h) return RBPF_EINVAL;
+    if (!h->scan_begun) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
+    h->scan_begun = false;
+    DevView& v = h->v;
     int rc = run_map_update(h);                 // HybridMap.update at the new mean pose (robot.py:115)
     if (rc) return rc;
     launch_bad_weight(v, h->d_bad, h->stream);  // robot.py:73-78 fallback, after the map update
@@ -622,9 +650,56 @@ int rbpf_set_global_ids(rbpf_handle* h, const int32_t* ids) {
 
 int rbpf_export_weights(rbpf_handle* h, void* d_global, int32_t n_global) {
     if (!h || !d_global || n_global < h->v.P) return RBPF_EINVAL;
-    launch_export_weights(h->v, static_cast<double*>(d_global), n_global, h->stream);
+    launch_export_weights(h->v, static_cast<double*>(d_global), n_global, nullptr, h->stream);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipStreamSynchronize(h->stream));        // the caller's collective may run on another stream
+    return RBPF_OK;                                     // stream-ordered: see the header about collectives on other streams
+}
+
+int rbpf_export_weights_early(rbpf_handle* h, void* d_global, int32_t n_global, void* aux_stream) {
+    if (!h || !d_global || n_global < h->v.P) return RBPF_EINVAL;
+    if (!h->ev_weights_valid) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
+    hipStream_t s = static_cast<hipStream_t>(aux_stream);
+    HIP_TRY(h, hipStreamWaitEvent(s, h->ev_weights, 0));
+    launch_export_weights(h->v, static_cast<double*>(d_global), n_global, h->d_bad, s);
+    HIP_TRY(h, hipGetLastError());
+    return RBPF_OK;
+}
+
+int rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global, int32_t n_global, double u, void* aux_stream) {
+    if (!h || !d_global || n_global < 1) return RBPF_EINVAL;
+    if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
+    hipStream_t s = static_cast<hipStream_t>(aux_stream);
+    int rc = scratch(h, &h->d_gT, &h->d_gT_cap, (size_t)n_global);
+    if (rc) return rc;
+    rc = scratch(h, &h->d_gidx, &h->d_gidx_cap, (size_t)n_global);
+    if (rc) return rc;
+    const size_t need = (size_t)n_global * 4 + 16;
+    if (need > h->h_early_bytes) {                       // pinned landing zone of the read-back
+        if (h->h_early) HIP_TRY(h, hipHostFree(h->h_early));
+        HIP_TRY(h, hipHostMalloc(&h->h_early, need, hipHostMallocDefault));
+        h->h_early_bytes = need;
+    }
+    launch_resample_indices(n_global, static_cast<const double*>(d_global), u, h->cfg.resample_spread, h->d_gT, h->d_gidx,
+                            h->d_did_early, h->v.err, s);
+    HIP_TRY(h, hipGetLastError());
+    unsigned char* dst = static_cast<unsigned char*>(h->h_early);
+    HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const double*>(d_global) + n_global, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(dst + 8, h->d_did_early, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(dst + 16, h->d_gidx, (size_t)n_global * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipEventRecord(h->ev_early, s));
+    h->early_n = n_global;
+    return RBPF_OK;                                      // nothing waited for: what is queued behind it keeps the GPU busy
+}
+
+int rbpf_resample_indices_global_wait(rbpf_handle* h, int32_t* idx_out, int32_t* did_resample, double* nan_branch_ranks) {
+    if (!h || !idx_out || !did_resample || !nan_branch_ranks) return RBPF_EINVAL;
+    if (h->early_n <= 0) return fail(h, RBPF_ESTATE, "rbpf_resample_indices_global_early has not been called");
+    HIP_TRY(h, hipEventSynchronize(h->ev_early));        // only up to the read-back, not the work queued after it
+    const unsigned char* src = static_cast<const unsigned char*>(h->h_early);
+    memcpy(nan_branch_ranks, src, 8);
+    memcpy(did_resample, src + 8, 4);
+    memcpy(idx_out, src + 16, (size_t)h->early_n * 4);
+    h->early_n = 0;
     return RBPF_OK;
 }
 
@@ -653,16 +728,19 @@ int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int3
         if (!ok) return fail(h, RBPF_EINVAL, "new_src must be sorted ascending with -1 entries last");
     }
     for (int j = 0; j < v.P; ++j) if (new_src[j] >= v.P) return fail(h, RBPF_EINVAL, "new_src out of range");
-    HIP_TRY(h, hipMemcpyAsync(h->rs.idx, new_src, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
+    int32_t* slot = static_cast<int32_t*>(h->ring_idx.acquire());   // pinned: the caller's arrays are free on return
+    memcpy(slot, new_src, (size_t)v.P * 4);
+    memcpy(slot + v.P, new_global_id, (size_t)v.P * 4);
+    HIP_TRY(h, hipMemcpyAsync(h->rs.idx, slot, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
     h->prof_begin(2);
     launch_sources_to_T(v.P, h->rs.idx, h->rs.T, h->rs.did, h->stream);
     launch_resample_apply(v, h->rs, h->stream);
     h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
-    HIP_TRY(h, hipMemcpyAsync(v.global_id, new_global_id, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));        // the host arrays may be reused by the caller; errors surface at the next check
-    return RBPF_OK;
+    HIP_TRY(h, hipMemcpyAsync(v.global_id, slot + v.P, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
+    h->ring_idx.submitted(h->stream);
+    return RBPF_OK;                                     // no host synchronisation; device errors surface at the next check
 }
 
 int32_t rbpf_pack_meta_width(rbpf_handle* h) { return h ? 2 + 6 * h->v.L * h->v.L : -1; }

@@ -96,7 +96,10 @@ struct rbpf_handle {
         void* acquire() { if (used[next]) (void)hipEventSynchronize(ev[next]); return base + (size_t)next * slot_bytes; }
         void submitted(hipStream_t s) { (void)hipEventRecord(ev[next], s); used[next] = true; next = (next + 1) % N; }
     };
-    PinnedRing ring_scan, ring_last;
+    PinnedRing ring_scan, ring_last, ring_idx;
+    hipEvent_t ev_weights = nullptr; bool ev_weights_valid = false;   // recorded after the weighting kernel of rbpf_scan_update_begin
+    int32_t* d_did_early = nullptr; bool scan_begun = false;
+    hipEvent_t ev_early = nullptr; void* h_early = nullptr; size_t h_early_bytes = 0; int early_n = 0;   // early resample read-back
     unsigned char* d_scan = nullptr; size_t scan_bytes = 0;   // device scan block, same layout as a ring_scan slot
     // scratch device buffers for test entries
     double* d_guess = nullptr; double* d_prs = nullptr; double* d_w = nullptr; size_t d_guess_n = 0;
@@ -131,7 +134,7 @@ void launch_imu_update(const DevView& v, int model, double d0, double d1, double
 void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
                              int32_t* d_did, int32_t* d_err, hipStream_t s);
 void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s);
-void launch_export_weights(const DevView& v, double* d_out, int n_global, hipStream_t s);
+void launch_export_weights(const DevView& v, double* d_out, int n_global, const uint8_t* d_bad, hipStream_t s);
 void launch_sources_to_T(int P, const int32_t* d_idx, int32_t* d_T, int32_t* d_did, hipStream_t s);
 void launch_gather_meta(const DevView& v, const int32_t* d_local, int n, int32_t* d_out, hipStream_t s);
 void launch_pack(const DevView& v, const void* d_jobs, int n_jobs, void* d_buf, hipStream_t s);

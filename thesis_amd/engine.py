@@ -152,6 +152,19 @@ class ParticleEngine:
             self._h, int(adj), None if ls is None else _dp(ls), 0 if ls is None else len(ls),
             None if mo is None else _dp(mo), None if gs is None else _dp(gs)))
 
+    def scan_update_begin(self, adj: bool = False, last_scan_xy=None, match_override=None, guesses=None):
+        """First half of scan_update: matcher, proposal, weighting (robot.py:62-114); follow with scan_update_end()."""
+        ls = None if last_scan_xy is None else _f64(last_scan_xy).reshape(-1, 2)
+        mo = None if match_override is None else _f64(match_override).reshape(self.P, 13)
+        gs = None if guesses is None else _f64(guesses).reshape(self.P, self.K, 3)
+        self._check(self._lib.rbpf_scan_update_begin(
+            self._h, int(adj), None if ls is None else _dp(ls), 0 if ls is None else len(ls),
+            None if mo is None else _dp(mo), None if gs is None else _dp(gs)))
+
+    def scan_update_end(self):
+        """Second half: the map update at the new mean pose and the NaN branch (robot.py:115, 73-78)."""
+        self._check(self._lib.rbpf_scan_update_end(self._h))
+
     def match_inputs(self, particle: int, guess, cap_ref: int = 1 << 16):
         """The (curr, ref) point lists HybridMap.get_scan_match would hand to the matcher (hybridmap.py:210-242)."""
         g = _f64(guess).reshape(3)

@@ -20,6 +20,9 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import os
+import time
+
 import numpy as np
 
 
@@ -33,47 +36,58 @@ class Plan:
     n_move: int
 
 
-def plan_migration(idx: np.ndarray, owner: np.ndarray, local_of: np.ndarray, world: int, p_local: int) -> Plan:
+def plan_migration(idx: np.ndarray, owner: np.ndarray, local_of: np.ndarray, world: int, p_local: int,
+                   rank: Optional[int] = None) -> Plan:
     """idx[j] = old global id continued by new global particle j; owner/local_of = rank and local index of
-    every old global particle.  Deterministic; every rank computes the same plan."""
+    every old global particle.  Deterministic; every rank computes the same plan.
+
+    Rule: a new particle stays on its ancestor's rank while that rank has room (first come in global order); the
+    surplus, taken rank by rank, fills the ranks that are short, lowest rank first.  Inside a rank the survivors
+    come first, ordered by their ancestor's old local index, then the arrivals, ordered by source rank; ties by
+    global id.
+
+    `rank` = r restricts the per-rank parts (new_gid, new_src, send rows) to what rank r itself needs: its own new
+    order, what it sends, and how many particles each rank sends to it (send[q][r] keeps only the right length).
+    This is what runs on every rank at every resample; it needs `local_of` only for the particles rank r owns."""
     idx = np.asarray(idx, dtype=np.int64)
     n = len(idx)
-    src_rank = owner[idx]
-    dest = np.full(n, -1, dtype=np.int32)
-    counts = np.zeros(world, dtype=np.int64)
-    surplus = []
-    for r in range(world):
-        js = np.nonzero(src_rank == r)[0]
-        keep = js[:p_local]
-        dest[keep] = r
-        counts[r] = len(keep)
-        surplus.append(js[p_local:])
-    pool = np.concatenate(surplus) if surplus else np.empty(0, dtype=np.int64)
-    k = 0
-    for d in range(world):
-        need = int(p_local - counts[d])
-        if need > 0:
-            dest[pool[k:k + need]] = d
-            k += need
-    assert k == len(pool) and (dest >= 0).all()
-    new_gid, new_src, send = [], [], [[np.empty(0, dtype=np.int32) for _ in range(world)] for _ in range(world)]
-    for r in range(world):
+    src_rank = np.asarray(owner)[idx].astype(np.int16)
+    by_rank = np.argsort(src_rank, kind="stable")                # grouped by ancestor rank, global order inside
+    cnt = np.bincount(src_rank, minlength=world)
+    first = np.concatenate(([0], np.cumsum(cnt)[:-1]))
+    pos = np.empty(n, dtype=np.int64)
+    pos[by_rank] = np.arange(n) - first[src_rank[by_rank]]       # position among the children of the same rank
+    keep = pos < p_local
+    dest = np.where(keep, src_rank, -1).astype(np.int16)
+    pool = by_rank[~keep[by_rank]]                               # surplus: rank by rank, global order inside
+    need = p_local - np.minimum(cnt, p_local)
+    assert int(need.sum()) == len(pool)
+    dest[pool] = np.repeat(np.arange(world), need)
+    movers = np.nonzero(dest != src_rank)[0]                     # global order
+    pair = src_rank[movers].astype(np.int64) * world + dest[movers]
+    n_pair = np.bincount(pair, minlength=world * world)
+    empty = np.empty(0, dtype=np.int32)
+    new_gid, new_src = [empty] * world, [empty] * world
+    send = [[empty] * world for _ in range(world)]
+    local_of = np.asarray(local_of)
+    for r in (range(world) if rank is None else (rank,)):
         js = np.nonzero(dest == r)[0]
-        kept = js[src_rank[js] == r]
-        anc_local = local_of[idx[kept]]
-        order = np.lexsort((kept, anc_local))                    # by ancestor's local index, then global id
-        kept, anc_local = kept[order], anc_local[order]
-        arr = js[src_rank[js] != r]
-        arr = arr[np.lexsort((arr, src_rank[arr]))]              # by source rank, then global id
-        new_gid.append(np.concatenate([kept, arr]).astype(np.int32))
-        new_src.append(np.concatenate([anc_local, np.full(len(arr), -1)]).astype(np.int32))
-    for r in range(world):
-        for d in range(world):
-            if d == r:
-                continue
-            js = np.nonzero((src_rank == r) & (dest == d))[0]
-            send[r][d] = local_of[idx[js]].astype(np.int32)
-    return Plan(dest, src_rank.astype(np.int32), new_gid, new_src, send, int((dest != src_rank).sum()))
+        arr = src_rank[js] != r
+        kept, came = js[~arr], js[arr]
+        anc = local_of[idx[kept]]
+        ko = np.lexsort((kept, anc))
+        co = np.lexsort((came, src_rank[came]))
+        new_gid[r] = np.concatenate([kept[ko], came[co]]).astype(np.int32)
+        new_src[r] = np.concatenate([anc[ko], np.full(len(came), -1)]).astype(np.int32)
+        mine = movers[src_rank[movers] == r]                     # what rank r sends, by destination then global id
+        o = np.argsort(dest[mine], kind="stable")
+        parts = np.split(local_of[idx[mine[o]]].astype(np.int32), np.cumsum(n_pair[r * world:(r + 1) * world])[:-1])
+        send[r] = list(parts)
+    if rank is not None:                                          # lengths of what arrives at `rank`
+        for q in range(world):
+            if q != rank:
+                send[q][rank] = np.zeros(int(n_pair[q * world + rank]), dtype=np.int32)
+    return Plan(dest.astype(np.int32), src_rank.astype(np.int32), new_gid, new_src, send, int(len(movers)))
 
 
 class EngineShard:
@@ -86,6 +100,11 @@ class EngineShard:
         self.device = torch.device("cuda", device)
         self.meta_width = int(engine._lib.rbpf_pack_meta_width(engine._h))
         self._buf = None
+        # the engine works on torch's current stream: its kernels, the collectives and the copies are then ordered
+        # without host synchronisation (the only one left per resample is reading the ancestor indices back)
+        engine.synchronize()
+        self.stream = torch.cuda.current_stream(self.device)
+        engine.set_stream(self.stream.cuda_stream)
 
     def set_global_ids(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
@@ -96,11 +115,29 @@ class EngineShard:
         self.e._check(self.e._lib.rbpf_export_weights(self.e._h, _vp(t.data_ptr()), n_global))
         return t
 
+    def weights_global_early(self, n_global):
+        """weights_global right after the weighting kernel of scan_update_begin, plus the NaN-branch flag element."""
+        t = self.torch.empty(n_global + 1, dtype=self.torch.float64, device=self.device)
+        self.e._check(self.e._lib.rbpf_export_weights_early(self.e._h, _vp(t.data_ptr()), n_global, _vp(self.stream.cuda_stream)))
+        return t
+
+    def indices_early(self, wglobal, u):
+        """Queue the ancestor computation and its read-back (no waiting)."""
+        self._early_n = wglobal.numel() - 1
+        self.e._check(self.e._lib.rbpf_resample_indices_global_early(self.e._h, _vp(wglobal.data_ptr()), self._early_n, float(u),
+                                                                     _vp(self.stream.cuda_stream)))
+
+    def indices_wait(self):
+        """(did, idx, any_bad) of the queued computation; waits for its read-back only."""
+        idx = np.empty(self._early_n, dtype=np.int32)
+        did, bad = _c.c_int32(), _c.c_double()
+        self.e._check(self.e._lib.rbpf_resample_indices_global_wait(self.e._h, idx.ctypes.data_as(_I32), _c.byref(did), _c.byref(bad)))
+        return bool(did.value), idx, bad.value != 0.0
+
     def indices(self, wglobal, u):
         n = wglobal.numel()
         idx = np.empty(n, dtype=np.int32)
         did = _c.c_int32()
-        self.torch.cuda.synchronize(self.device)
         self.e._check(self.e._lib.rbpf_resample_indices_global(self.e._h, _vp(wglobal.data_ptr()), n, float(u),
                                                                idx.ctypes.data_as(_I32), _c.byref(did)))
         return bool(did.value), idx
@@ -173,6 +210,7 @@ class ShardedResampler:
         self.local_of = (g % p_local).astype(np.int32)     # its index inside that rank's engine
         self.shard = None
         self.stats = {"resamples": 0, "moved": 0, "bytes_sent": 0}
+        self.timing = {} if os.environ.get("RBPF_SHARD_TIMING") else None   # developer aid: host seconds per phase
 
     def attach(self, engine_or_shard):
         self.shard = engine_or_shard if hasattr(engine_or_shard, "weights_global") else EngineShard(engine_or_shard, self.device or 0)
@@ -198,27 +236,80 @@ class ShardedResampler:
         return recv.to(dev) if recv.device != dev else recv
 
     # -- the step --------------------------------------------------------------------------------------------------------
+    def _book(self, plan):
+        """Ownership of every new global particle (replicated); local indices only of this rank's own particles."""
+        self.owner[:] = plan.dest
+        mine = plan.new_gid[self.rank]
+        self.local_of[mine] = np.arange(len(mine), dtype=np.int32)
+
+    def _tick(self, name, t0):
+        if self.timing is not None:
+            self.timing[name] = self.timing.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    def resample_begin(self, u: float):
+        """Call between scan_update_begin and scan_update_end: the weight export, the collective, the ancestor
+        computation and its read-back are queued BEFORE the map update, so that the host gets the ancestors, plans the
+        migration and queues the tile copies while the GPU runs the map update.  Falls back to nothing
+        (resample_finish does all the work) for shards without the early calls or a host-staged transport."""
+        self._early, self._u = None, u
+        sh = self.shard
+        if self.host_staged or not hasattr(sh, "weights_global_early"):
+            return
+        t0 = time.perf_counter()
+        wl = sh.weights_global_early(self.n_global)
+        self.dist.all_reduce(wl)                                             # the one collective on the weights
+        sh.indices_early(wl, u)
+        self._early = wl
+        self._tick("early_queue", t0)
+
+    def resample_finish(self) -> Tuple[bool, Optional[np.ndarray]]:
+        """Call after scan_update_end.  Uses the early result unless a particle took the NaN-covariance branch (its
+        weight changed after the map update, robot.py:73-78); then the whole resample runs late, as resample()."""
+        if getattr(self, "_early", None) is None:
+            return self.resample(self._u)
+        t0 = time.perf_counter()
+        did, idx, any_bad = self.shard.indices_wait()
+        self._early = None
+        t0 = self._tick("indices_wait", t0)
+        if any_bad:                                                          # the same on every rank (part of the collective)
+            self.stats["late"] = self.stats.get("late", 0) + 1
+            return self.resample(self._u)
+        return self._apply(did, idx)
+
     def resample(self, u: float) -> Tuple[bool, Optional[np.ndarray]]:
-        sh, torch = self.shard, self.torch
-        w = self._all_reduce(sh.weights_global(self.n_global))              # the one collective on the weights
+        sh = self.shard
+        t0 = time.perf_counter()
+        wl = sh.weights_global(self.n_global)
+        t0 = self._tick("export", t0)
+        w = self._all_reduce(wl)                                             # the one collective on the weights
+        t0 = self._tick("all_reduce", t0)
         did, idx = sh.indices(w, u)
+        t0 = self._tick("indices", t0)
+        return self._apply(did, idx)
+
+    def _apply(self, did, idx) -> Tuple[bool, Optional[np.ndarray]]:
+        sh, torch = self.shard, self.torch
+        t0 = time.perf_counter()
         if not did:
             return False, None
-        plan = plan_migration(idx, self.owner, self.local_of, self.world, self.p_local)
+        plan = plan_migration(idx, self.owner, self.local_of, self.world, self.p_local, rank=self.rank)
+        t0 = self._tick("plan", t0)
         r, W = self.rank, sh.meta_width
         if plan.n_move == 0:                                                 # every rank sees the same plan: no exchange
             sh.apply_local(plan.new_src[r], plan.new_gid[r])
-            for q in range(self.world):
-                self.owner[plan.new_gid[q]] = q
-                self.local_of[plan.new_gid[q]] = np.arange(len(plan.new_gid[q]), dtype=np.int32)
+            t0 = self._tick("apply_local", t0)
+            self._book(plan)
             self.stats["resamples"] += 1
             return True, idx
-        # pack what leaves this rank, destination by destination
-        metas, payloads, n_out, b_out = [], [], [], []
-        for d in range(self.world):
-            li = plan.send[r][d]
-            m, p = sh.pack(li) if len(li) else (np.zeros((0, W), dtype=np.int32), sh.empty_payload(0))
-            metas.append(m); payloads.append(p); n_out.append(len(li)); b_out.append(int(p.numel()))
+        # pack what leaves this rank in ONE call, ordered by destination (one gather of the metadata, one kernel);
+        # the per-destination byte counts follow from the metadata rows (16-byte units in column 1)
+        n_out = [len(plan.send[r][d]) for d in range(self.world)]
+        leaving = np.concatenate([np.asarray(plan.send[r][d], dtype=np.int32) for d in range(self.world)]) if sum(n_out) else np.zeros(0, dtype=np.int32)
+        meta_all, pay_all = sh.pack(leaving)
+        ends = np.cumsum(n_out)
+        b_out = [int(meta_all[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_out, ends)]
+        metas, payloads = [meta_all], [pay_all]
         n_in = [len(plan.send[q][r]) for q in range(self.world)]
         if sum(n_out) + sum(n_in) > 0 or self.world > 1:
             dev = payloads[0].device
@@ -236,10 +327,7 @@ class ShardedResampler:
         sh.apply_local(plan.new_src[r], plan.new_gid[r])
         arrivals = np.nonzero(plan.new_src[r] < 0)[0].astype(np.int32)
         sh.unpack(arrivals, meta_in, pay_recv)
-        # replicated bookkeeping
-        for q in range(self.world):
-            self.owner[plan.new_gid[q]] = q
-            self.local_of[plan.new_gid[q]] = np.arange(len(plan.new_gid[q]), dtype=np.int32)
+        self._book(plan)
         self.stats["resamples"] += 1
         self.stats["moved"] += plan.n_move
         self.stats["bytes_sent"] += sum(b_out)
