@@ -261,6 +261,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     __shared__ int s_cntc[MAXLEV + 1], s_fill[MAXLEV + 1], s_lp[MAXLEV + 1], s_nk[MAXLEV + 1];
     __shared__ int s_wsum[FB / 64];
     __shared__ int s_nflag, s_nmark, s_nbig, s_nslow, s_ev, s_written;
+    __shared__ int s_wq, s_pq[8];           // work queues: waves fetch 64 items at a time (walk; write-back per tile)
     __shared__ unsigned long long s_cells;
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     if (tid == 0) {
         s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
         s_cells = 0; s_fb = 0; s_written = 0;
-        s_nflag = 0; s_nmark = 0; s_nbig = 0; s_nslow = 0; s_ev = 0;
+        s_nflag = 0; s_nmark = 0; s_nbig = 0; s_nslow = 0; s_ev = 0; s_wq = 0;
+        for (int i = 0; i < 8; ++i) s_pq[i] = 0;
     }
     if (tid <= MAXLEV) { s_cntc[tid] = 0; s_fill[tid] = 0; }
     for (int i = tid; i < LL; i += FB) { s_need[i] = 0; s_tab[i] = tab[i]; }
@@ -542,8 +544,12 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
 #pragma unroll
         for (int k = 0; k < MAXLEV; ++k) lpk[k] = UNI(s_lp[k]);
         const int nitems = UNI(s_lp[MAXLEV]);
-        for (int q = tid; q < nitems; q += FB) {
-            const int qw = UNI(q);                                                 // levels are whole waves: every lane shares k
+        for (;;) {                                                                 // a wave takes the next 64 items: waves that
+            int qw = 0;                                                            // got cheap items take more
+            if (lane == 0) qw = atomicAdd(&s_wq, 64);
+            qw = UNI(qw);                                                          // levels are whole waves: every lane shares k
+            if (qw >= nitems) break;
+            const int q = qw + lane;
             int k = 0, base = 0, nxt = lpk[1];
 #pragma unroll
             for (int kk = 1; kk < MAXLEV; ++kk) if (qw >= lpk[kk]) { k = kk; base = lpk[kk]; nxt = kk + 1 < MAXLEV ? lpk[kk + 1] : nitems; }
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     //      unflagged cell: v = max(v + n*emp, min) (gridmap.py:97-101, n times); flagged cell: the replayed value.
     //      The group's word of the tile's occupancy bitmask (cell > threshold, gridmap.py:153) is rebuilt.
     {
-        int my_written = 0;
+        int my_written = 0, combo = 0;
         const int eabs = -v.cc.emp;
         const uint32_t kb1 = (uint32_t)(128 + v.cc.vmin) * 0x01010101u;             // byte-wise: (cell ^ 0x80) - kb1 = cell - vmin
         const uint32_t satb = sat * 0x01010101u, sadd = (128u - sat) * 0x01010101u;
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             const int ngr = g_hi - g_lo + 1, items = (wx_hi - wx_lo + 1) * ngr;
             int8_t* __restrict__ tile_base = v.pool + (size_t)tile * v.dim * v.dim;
             int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
-            for (int it = tid; it < items; it += FB) {
+            auto write_back = [&](int it) {
                 const int rr = it / ngr, gg = it - rr * ngr;
                 const int wx = wx_lo + rr, Gy = g_lo + gg;
                 const int row = wx + Ux0 - a * v.dim, col = 32 * Gy - bt * v.dim;
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                     n[w] = (wyw >= 0 && wyw < stride) ? cnt[(wx * stride + wyw) >> 2] : 0u;
                     any |= n[w];
                 }
-                if (!any) continue;
+                if (!any) return;
                 uint32_t* const g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)row * v.dim + col);
                 uint32_t pre[8];
                 {
@@ -871,7 +877,22 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                 by0 = min(by0, col + __ffs(touched) - 1); by1 = max(by1, col + 31 - __clz(touched));
                 v.occ[((size_t)tile * v.dim + row) * v.ow + (col >> 5)] = occ;
                 bx0 = min(bx0, row); bx1 = max(bx1, row);
+            };
+            // waves fetch 64 items at a time: groups without a touched cell cost next to nothing, so a static split
+            // would leave some waves with most of the work
+            const int ci = combo++;                                                // uniform over the workgroup
+            if (ci < 8) {
+                while (true) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_pq[ci], 64);
+                    base = UNI(base);
+                    if (base >= items) break;
+                    if (base + lane < items) write_back(base + lane);
+                }
+            } else {
+                for (int it = tid; it < items; it += FB) write_back(it);
             }
+
             bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
             if (lane == 0 && bx1 >= 0) {                                           // this workgroup is the tile's only writer
                 atomicMin(&v.tile_bbox[4 * tile + 0], bx0); atomicMax(&v.tile_bbox[4 * tile + 1], bx1);
