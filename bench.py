@@ -63,10 +63,21 @@ class Runner:
         # cold start: the first scan goes into every map at the origin (update_count < 2 branch, main.py:155)
         self.e.set_scan(self.ranges[0], self.angles)
         self.e.map_update(np.zeros((P, 3)))
+        self.host_last_scan = shard is not None and shard.host_staged      # gloo rehearsals keep the host path
         self._refresh_last_scan(0, np.zeros(3))
 
-    def _refresh_last_scan(self, k, pose0):
-        # main.py:167-168: last_scan = scan.from_global_reference(particles[0].get_latest_pose())
+    def _refresh_last_scan(self, k, pose0=None):
+        # main.py:167-168: last_scan = scan.from_global_reference(particles[0].get_latest_pose()); on the device (the
+        # current scan is scan k): nothing is read back, the host keeps running ahead of the GPU
+        if not self.host_last_scan:
+            self.last_scan_xy = None
+            if self.shard is None:
+                self.e.refresh_last_scan(0)
+            else:
+                self.shard.refresh_last_scan()
+            return
+        if pose0 is None:
+            pose0 = self.shard.pose_of_particle0()
         r, a = self.ranges[k], self.angles
         c, s = np.cos(pose0[2]), np.sin(pose0[2])
         x, y = r * np.cos(a), r * np.sin(a)
@@ -88,8 +99,7 @@ class Runner:
             e.scan_update_end()
             self.shard.resample_finish()
         if k % 5 == 0:                                                        # main.py:167
-            pose0 = e.poses()[0] if self.shard is None else self.shard.pose_of_particle0()
-            self._refresh_last_scan(k + 1, pose0)
+            self._refresh_last_scan(k + 1)
         self.frame += 1
 
 

@@ -136,6 +136,14 @@ int  rbpf_map_update(rbpf_handle* h, const double* poses);
  *                  (replaces np.random.multivariate_normal, robot.py:81)                       */
 int  rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
                       const double* match_override, const double* guesses);
+/* main.py:167-168: last_scan = scan.from_global_reference(particles[0].get_latest_pose()).  Computed on the device
+ * from the current scan and the pose of `particle`, and kept there: a later rbpf_scan_update with adj = 1 and
+ * last_scan_xy = NULL uses it, so the driver loop never has to read a pose back.  rbpf_export_last_scan /
+ * rbpf_import_last_scan copy it to / from a device buffer of max_beams * 2 doubles (stream-ordered), for the rank
+ * that owns particle 0 to broadcast it in a multi-GPU job. */
+int  rbpf_refresh_last_scan(rbpf_handle* h, int32_t particle);
+int  rbpf_export_last_scan(rbpf_handle* h, void* d_out_xy, int32_t* n_points);
+int  rbpf_import_last_scan(rbpf_handle* h, const void* d_xy, int32_t n_points);
 /* The same in two halves, for a driver that wants the weights as early as possible (multi-GPU resampling):
  * _begin = scan matcher, proposal, weighting, moments (robot.py:62-114): the weights are final here unless a particle
  * took the NaN-covariance branch; _end = the map update at the new mean pose and that branch (robot.py:115, 73-78). */

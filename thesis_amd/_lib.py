@@ -61,6 +61,9 @@ PROTOTYPES = {
     "rbpf_weight_samples": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
     "rbpf_map_update": (C.c_int, [_H, _D]),
     "rbpf_scan_update": (C.c_int, [_H, C.c_int32, _D, C.c_int32, _D, _D]),
+    "rbpf_refresh_last_scan": (C.c_int, [_H, C.c_int32]),
+    "rbpf_export_last_scan": (C.c_int, [_H, C.c_void_p, _I]),
+    "rbpf_import_last_scan": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "rbpf_scan_update_begin": (C.c_int, [_H, C.c_int32, _D, C.c_int32, _D, _D]),
     "rbpf_scan_update_end": (C.c_int, [_H]),
     "rbpf_match_scan": (C.c_int, [_H, _D, C.c_int32, _D, C.c_int32, _D, C.c_int32, _D, _D, _D, _D]),

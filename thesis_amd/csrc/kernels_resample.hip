@@ -61,7 +61,7 @@ struct ResampleArgs {
 };
 
 // ---- kernel 1: trigger test, weight shift, double-double prefix sums, T array --------------------------
-__global__ __launch_bounds__(PLAN_THREADS) void resample_plan_kernel(ResampleArgs a) {
+__device__ void resample_plan_stage(const ResampleArgs& a) {
     __shared__ double s_red[PLAN_THREADS];
     __shared__ double s_hi[PLAN_THREADS], s_lo[PLAN_THREADS];
     __shared__ double s_max, s_min, s_min2;
@@ -132,9 +132,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void resample_plan_kernel(ResampleArg
 }
 
 // ---- kernel 2: ancestors by binary search over T -----------------------------------------------------
-__global__ void resample_expand_kernel(int P, const int32_t* __restrict__ T, int32_t* __restrict__ idx) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P) return;
+__device__ __forceinline__ void resample_expand_one(int P, const int32_t* __restrict__ T, int32_t* __restrict__ idx, int j) {
     int lo = 0, hi = P - 1;                                  // first i with T[i] > j
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -168,7 +166,7 @@ __device__ int block_exclusive_scan_1024(int val, int* s_buf, int tid, int& tota
     return s_buf[tid] - val;
 }
 
-__global__ __launch_bounds__(PLAN_THREADS) void resample_pair_kernel(PairArgs a) {
+__device__ void resample_pair_stage(const PairArgs& a) {
     __shared__ int s_buf[PLAN_THREADS];
     const int tid = threadIdx.x, nt = PLAN_THREADS;
     const int chunk = (a.P + nt - 1) / nt;
@@ -219,9 +217,7 @@ struct GatherArgs {
     const double *px, *py, *pth, *cov, *w;
     double *px2, *py2, *pth2, *cov2, *w2;
 };
-__global__ void resample_gather_kernel(GatherArgs a) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= a.P) return;
+__device__ __forceinline__ void resample_gather_one(const GatherArgs& a, int j) {
     const int i = a.idx[j];
     if (i < 0) return;                 // arrives from another rank: filled by the unpack kernel
     a.px2[j] = a.px[i]; a.py2[j] = a.py[i]; a.pth2[j] = a.pth[i];
@@ -368,8 +364,7 @@ __global__ void export_weights_kernel(int P, const double* __restrict__ w, const
 }
 
 // T[i] = number of new local particles whose source is an old local particle <= i (sources sorted ascending, -1 last)
-__global__ __launch_bounds__(PLAN_THREADS) void sources_to_T_kernel(int P, const int32_t* __restrict__ idx, int32_t* __restrict__ T,
-                                                                     int32_t* __restrict__ did) {
+__device__ void sources_to_T_stage(int P, const int32_t* __restrict__ idx, int32_t* __restrict__ T, int32_t* __restrict__ did) {
     __shared__ int s_buf[PLAN_THREADS];
     const int tid = threadIdx.x, nt = PLAN_THREADS;
     const int chunk = (P + nt - 1) / nt;
@@ -493,6 +488,35 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJo
     if (tid == 0) { v.tile_bbox[4 * td + 0] = j.x0; v.tile_bbox[4 * td + 1] = j.x1; v.tile_bbox[4 * td + 2] = j.ya; v.tile_bbox[4 * td + 3] = j.yb - 1; }
 }
 
+// ---- kernels: the stages one by one (any P), or the small ones fused into one single-workgroup launch ------------
+__global__ __launch_bounds__(PLAN_THREADS) void resample_plan_kernel(ResampleArgs a) { resample_plan_stage(a); }
+__global__ void resample_expand_kernel(int P, const int32_t* __restrict__ T, int32_t* __restrict__ idx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P) resample_expand_one(P, T, idx, j);
+}
+__global__ __launch_bounds__(PLAN_THREADS) void resample_pair_kernel(PairArgs a) { resample_pair_stage(a); }
+__global__ void resample_gather_kernel(GatherArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < a.P) resample_gather_one(a, j);
+}
+__global__ __launch_bounds__(PLAN_THREADS) void sources_to_T_kernel(int P, const int32_t* __restrict__ idx, int32_t* __restrict__ T,
+                                                                     int32_t* __restrict__ did) { sources_to_T_stage(P, idx, T, did); }
+
+// The planning stages are single-workgroup or trivially parallel; for moderate P one workgroup runs them back to back
+// (a stage reads what the previous one wrote to global memory: same CU, __syncthreads() orders it), which saves
+// three kernel launches and their dispatch gaps per resample.
+enum { RS_PLAN = 1, RS_SRC2T = 2, RS_EXPAND = 4, RS_PAIR = 8, RS_GATHER = 16 };
+static const int RS_FUSE_MAX = 16384;
+struct FusedArgs { int stages; ResampleArgs ra; int32_t* idx; PairArgs pa; GatherArgs ga; };
+__global__ __launch_bounds__(PLAN_THREADS) void resample_fused_kernel(FusedArgs f) {
+    const int tid = threadIdx.x;
+    if (f.stages & RS_PLAN) { resample_plan_stage(f.ra); __syncthreads(); }
+    if (f.stages & RS_SRC2T) { sources_to_T_stage(f.ra.P, f.idx, f.ra.T, f.ra.did); __syncthreads(); }
+    if (f.stages & RS_EXPAND) { for (int j = tid; j < f.ra.P; j += PLAN_THREADS) resample_expand_one(f.ra.P, f.ra.T, f.idx, j); __syncthreads(); }
+    if (f.stages & RS_PAIR) { resample_pair_stage(f.pa); __syncthreads(); }
+    if (f.stages & RS_GATHER) for (int j = tid; j < f.ga.P; j += PLAN_THREADS) resample_gather_one(f.ga, j);
+}
+
 void launch_export_weights(const DevView& v, double* d_out, int n_global, const uint8_t* d_bad, hipStream_t s) {
     (void)hipMemsetAsync(d_out, 0, (size_t)(n_global + (d_bad ? 1 : 0)) * 8, s);
     hipLaunchKernelGGL(export_weights_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, v.P, v.weight, v.global_id, d_out, n_global, d_bad);
@@ -517,8 +541,45 @@ void launch_unpack(const DevView& v, const ResampleBuffers& b, const void* d_job
 void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
                              int32_t* d_did, int32_t* d_err, hipStream_t s) {
     ResampleArgs ra{P, d_w, u, spread, d_T, d_did, d_err};
+    if (P <= RS_FUSE_MAX) {
+        FusedArgs f{RS_PLAN | RS_EXPAND, ra, d_idx, PairArgs{}, GatherArgs{}};
+        hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
+        return;
+    }
     hipLaunchKernelGGL(resample_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, ra);
     hipLaunchKernelGGL(resample_expand_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, d_T, d_idx);
+}
+
+// the whole local resample (main.py:46-79): plan, ancestors, slot pairing, state permutation, tile copies
+void launch_resample_local(const DevView& v, const ResampleBuffers& b, const double* d_w, double u, double spread, hipStream_t s) {
+    if (v.P > RS_FUSE_MAX) {
+        launch_resample_indices(v.P, d_w, u, spread, b.T, b.idx, b.did, v.err, s);
+        launch_resample_apply(v, b, s);
+        return;
+    }
+    FusedArgs f{RS_PLAN | RS_EXPAND | RS_PAIR | RS_GATHER, ResampleArgs{v.P, d_w, u, spread, b.T, b.did, v.err}, b.idx,
+                PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
+                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2}};
+    hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
+    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
+    hipLaunchKernelGGL(resample_copy_kernel, dim3(1024), dim3(BLOCK), 0, s, ca);
+    hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
+}
+
+// the local part of a global resample: new_src (sorted sources, -1 = arrival) in b.idx -> T, slots, state, tile copies
+void launch_resample_apply_sources(const DevView& v, const ResampleBuffers& b, hipStream_t s) {
+    if (v.P > RS_FUSE_MAX) {
+        launch_sources_to_T(v.P, b.idx, b.T, b.did, s);
+        launch_resample_apply(v, b, s);
+        return;
+    }
+    FusedArgs f{RS_SRC2T | RS_PAIR | RS_GATHER, ResampleArgs{v.P, nullptr, 0.0, 0.0, b.T, b.did, v.err}, b.idx,
+                PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
+                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2}};
+    hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
+    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
+    hipLaunchKernelGGL(resample_copy_kernel, dim3(1024), dim3(BLOCK), 0, s, ca);
+    hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
 
 void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s) {

@@ -87,4 +87,20 @@ void launch_imu_update(const DevView& v, int model, double d0, double d1, double
                        dt_ticks, vn[0], vn[1], vn[2], vn[3]);
 }
 
+// main.py:167-168: last_scan = scan.from_global_reference(particles[0].get_latest_pose()) - the current scan in the
+// global frame of one particle's pose (lidar.py:111-128), kept on the device for the next get_scan_adj calls
+__global__ void last_scan_kernel(DevView v, int particle, double* __restrict__ out_xy) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= v.B) return;
+    double sn, cs;
+    sincos(v.pth[particle], &sn, &cs);
+    const double x = v.bx[b], y = v.by[b];
+    out_xy[2 * b] = (cs * x + (-sn) * y) + v.px[particle];                          // lidar.py:123
+    out_xy[2 * b + 1] = (sn * x + cs * y) + v.py[particle];
+}
+
+void launch_last_scan(const DevView& v, int particle, double* d_out_xy, hipStream_t s) {
+    hipLaunchKernelGGL(last_scan_kernel, dim3((v.B + 255) / 256), dim3(256), 0, s, v, particle, d_out_xy);
+}
+
 }  // namespace rbpf

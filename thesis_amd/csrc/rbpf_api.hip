@@ -473,9 +473,12 @@ int rbpf_map_update(rbpf_handle* h, const double* poses) {
 
 static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last) {
     DevView& v = h->v;
-    if (adj && (!last_scan_xy || n_last < 0 || n_last > h->cfg.max_beams))
+    if (adj && !last_scan_xy) {                 // the device-resident previous scan (rbpf_refresh_last_scan / rbpf_import_last_scan)
+        if (h->n_last_dev < 0) return fail(h, RBPF_ESTATE, "adj = 1 without last_scan_xy needs rbpf_refresh_last_scan first");
+        n_last = h->n_last_dev;
+    } else if (adj && (n_last < 0 || n_last > h->cfg.max_beams))
         return fail(h, RBPF_EINVAL, "adj = 1 needs last_scan_xy with at most max_beams points");
-    if (adj) {
+    if (adj && last_scan_xy) {
         void* slot = h->ring_last.acquire();
         memcpy(slot, last_scan_xy, (size_t)n_last * 16);
         HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, slot, (size_t)n_last * 16, hipMemcpyHostToDevice, h->stream));
@@ -629,8 +632,7 @@ int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resam
     if (u != u) u = internal_uniform(h);
     if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
     h->prof_begin(2);
-    launch_resample_indices(v.P, v.weight, u, h->cfg.resample_spread, h->rs.T, h->rs.idx, h->rs.did, v.err, h->stream);
-    launch_resample_apply(v, h->rs, h->stream);
+    launch_resample_local(v, h->rs, v.weight, u, h->cfg.resample_spread, h->stream);
     h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
@@ -733,8 +735,7 @@ int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int3
     memcpy(slot + v.P, new_global_id, (size_t)v.P * 4);
     HIP_TRY(h, hipMemcpyAsync(h->rs.idx, slot, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
     h->prof_begin(2);
-    launch_sources_to_T(v.P, h->rs.idx, h->rs.T, h->rs.did, h->stream);
-    launch_resample_apply(v, h->rs, h->stream);
+    launch_resample_apply_sources(v, h->rs, h->stream);
     h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
@@ -892,6 +893,31 @@ static int fetch_tab(rbpf_handle* h, int32_t particle, std::vector<int32_t>& tab
     HIP_TRY(h, hipMemcpy(&slot, h->v.slot + particle, 4, hipMemcpyDeviceToHost));
     tab.resize(LL);
     HIP_TRY(h, hipMemcpy(tab.data(), h->v.tile_tab + (size_t)slot * LL, LL * 4, hipMemcpyDeviceToHost));
+    return RBPF_OK;
+}
+
+int rbpf_refresh_last_scan(rbpf_handle* h, int32_t particle) {
+    if (!h) return RBPF_EINVAL;
+    if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
+    if (particle < 0 || particle >= h->v.P) return fail(h, RBPF_EINVAL, "particle out of range");
+    launch_last_scan(h->v, particle, h->d_last_xy, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    h->n_last_dev = h->v.B;
+    return RBPF_OK;
+}
+
+int rbpf_export_last_scan(rbpf_handle* h, void* d_out_xy, int32_t* n_points) {
+    if (!h || !d_out_xy || !n_points) return RBPF_EINVAL;
+    if (h->n_last_dev < 0) return fail(h, RBPF_ESTATE, "no device-resident previous scan");
+    HIP_TRY(h, hipMemcpyAsync(d_out_xy, h->d_last_xy, (size_t)h->n_last_dev * 16, hipMemcpyDeviceToDevice, h->stream));
+    *n_points = h->n_last_dev;
+    return RBPF_OK;
+}
+
+int rbpf_import_last_scan(rbpf_handle* h, const void* d_xy, int32_t n_points) {
+    if (!h || !d_xy || n_points < 0 || n_points > h->cfg.max_beams) return RBPF_EINVAL;
+    HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, d_xy, (size_t)n_points * 16, hipMemcpyDeviceToDevice, h->stream));
+    h->n_last_dev = n_points;
     return RBPF_OK;
 }
 

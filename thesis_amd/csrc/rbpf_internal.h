@@ -105,6 +105,7 @@ struct rbpf_handle {
     double* d_guess = nullptr; double* d_prs = nullptr; double* d_w = nullptr; size_t d_guess_n = 0;
     int mN = 0, mds = 1, mncr = 0; double mmcs = 0, md0 = 0; size_t mlds = 0;
     double* d_last_xy = nullptr; float* d_tmp_sel = nullptr;
+    int n_last_dev = -1;                       // points of the device-resident previous scan (rbpf_refresh_last_scan), -1 = none
     double* d_match = nullptr; uint8_t* d_bad = nullptr; double* d_guess_full = nullptr;
     unsigned long long resample_draws = 0;
     int32_t* d_gT = nullptr; size_t d_gT_cap = 0; int32_t* d_gidx = nullptr; size_t d_gidx_cap = 0;
@@ -129,11 +130,14 @@ bool map_update_fan_available(const DevView& v);
 void launch_map_update_fan(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
+void launch_last_scan(const DevView& v, int particle, double* d_out_xy, hipStream_t s);
 void launch_imu_update(const DevView& v, int model, double d0, double d1, double d2, double dt_ticks,
                        const double* vel_noise, hipStream_t s);
 void launch_resample_indices(int P, const double* d_w, double u, double spread, int32_t* d_T, int32_t* d_idx,
                              int32_t* d_did, int32_t* d_err, hipStream_t s);
 void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream_t s);
+void launch_resample_local(const DevView& v, const ResampleBuffers& b, const double* d_w, double u, double spread, hipStream_t s);
+void launch_resample_apply_sources(const DevView& v, const ResampleBuffers& b, hipStream_t s);
 void launch_export_weights(const DevView& v, double* d_out, int n_global, const uint8_t* d_bad, hipStream_t s);
 void launch_sources_to_T(int P, const int32_t* d_idx, int32_t* d_T, int32_t* d_did, hipStream_t s);
 void launch_gather_meta(const DevView& v, const int32_t* d_local, int n, int32_t* d_out, hipStream_t s);

@@ -152,6 +152,11 @@ class ParticleEngine:
             self._h, int(adj), None if ls is None else _dp(ls), 0 if ls is None else len(ls),
             None if mo is None else _dp(mo), None if gs is None else _dp(gs)))
 
+    def refresh_last_scan(self, particle: int = 0):
+        """main.py:167-168 on the device: the current scan at `particle`'s pose becomes the previous scan that
+        scan_update(adj=True, last_scan_xy=None) matches against."""
+        self._check(self._lib.rbpf_refresh_last_scan(self._h, int(particle)))
+
     def scan_update_begin(self, adj: bool = False, last_scan_xy=None, match_override=None, guesses=None):
         """First half of scan_update: matcher, proposal, weighting (robot.py:62-114); follow with scan_update_end()."""
         ls = None if last_scan_xy is None else _f64(last_scan_xy).reshape(-1, 2)

@@ -333,6 +333,22 @@ class ShardedResampler:
         self.stats["bytes_sent"] += sum(b_out)
         return True, idx
 
+    def refresh_last_scan(self):
+        """main.py:167-168 for a sharded filter, on the device: the rank that holds global particle 0 transforms the
+        current scan to that particle's pose and broadcasts the points; every rank keeps them as the previous scan
+        for scan_update(adj=True).  No pose is read back, nothing waits on the host."""
+        torch, e = self.torch, self.shard.e
+        src = int(self.owner[0])
+        buf = torch.empty(2 * int(e.cfg.max_beams), dtype=torch.float64, device=self.shard.device)
+        n = _c.c_int32(e.n_beams)
+        if self.rank == src:
+            e.refresh_last_scan(int(self.local_of[0]))
+            e._check(e._lib.rbpf_export_last_scan(e._h, _vp(buf.data_ptr()), _c.byref(n)))
+        if self.world > 1:
+            self.dist.broadcast(buf, src=src)
+        if self.rank != src:
+            e._check(e._lib.rbpf_import_last_scan(e._h, _vp(buf.data_ptr()), e.n_beams))
+
     def pose_of_particle0(self) -> np.ndarray:
         """main.py:152,167: particles[0].get_latest_pose(), from whichever rank holds global particle 0."""
         torch = self.torch
