@@ -21,25 +21,27 @@ __device__ __forceinline__ bool lookup_cell(const DevView& v, const int32_t* __r
     return true;
 }
 
-// Same result as lookup_cell with one multiply-add per axis instead of four float64 divisions: the quotients are
-// evaluated approximately and the reference's exact expressions (gridmap.py:126, hybridmap.py:44-45) are used only
-// when an approximate value lies within 1e-6 of an integer, i.e. when the two could truncate differently.
+// Same result as lookup_cell with two multiplications per axis instead of four float64 divisions.  A position is
+// resolved through its global cell number floor(x / cell_size): every bound the reference compares against - the tile
+// bounds of hybridmap.py:44-45 and the integer steps of gridmap.py:126 - is a multiple of cell_size up to rounding
+// (tile_len = dim * cell_size), so the exact expressions are needed only when x / cell_size lies within 1e-6 of an
+// integer, i.e. when the two could pick different cells.
 __device__ __forceinline__ bool lookup_cell_fast(const DevView& v, const int32_t* __restrict__ tab,
                                                  double gx, double gy, int& val) {
-    const double half = v.tile_len * 0.5, inv_len = 1.0 / v.tile_len, scale = (double)v.dim * inv_len, hd = (double)v.dim * 0.5;
-    const double tx = (gx + half) * inv_len, ty = (gy + half) * inv_len;
-    const double fxl = __builtin_floor(tx), fyl = __builtin_floor(ty);
-    const double qx = (gx - fxl * v.tile_len) * scale + hd, qy = (gy - fyl * v.tile_len) * scale + hd;   // in [0, dim)
-    const double rx = qx - __builtin_floor(qx), ry = qy - __builtin_floor(qy);
-    const double ux = tx - fxl, uy = ty - fyl;
+    const double inv_cs = (double)v.dim / v.tile_len, inv_dim = 1.0 / (double)v.dim, hd = (double)(v.dim / 2);
+    const double cx = gx * inv_cs, cy = gy * inv_cs;                               // in cells
+    const double fx = __builtin_floor(cx), fy = __builtin_floor(cy);
+    const double rx = cx - fx, ry = cy - fy;
     const double eps = 1e-6;
-    if (!(rx > eps && rx < 1 - eps && ry > eps && ry < 1 - eps && ux > eps && ux < 1 - eps && uy > eps && uy < 1 - eps))
+    if (!(rx > eps && rx < 1 - eps && ry > eps && ry < 1 - eps) || (v.dim & 1))
         return lookup_cell(v, tab, gx, gy, val);
-    const int lx = (int)fxl, ly = (int)fyl;
+    const double lxf = __builtin_floor((fx + hd) * inv_dim), lyf = __builtin_floor((fy + hd) * inv_dim);   // tile lattice coordinate
+    const int lx = (int)lxf, ly = (int)lyf;
     if (lx < -v.R || lx > v.R || ly < -v.R || ly > v.R) return false;
     const int t = tab[(lx + v.R) * v.L + (ly + v.R)];
     if (t < 0) return false;
-    val = v.pool[(size_t)t * v.dim * v.dim + (size_t)(int)qx * v.dim + (int)qy];
+    const int ix = (int)fx - lx * v.dim + v.dim / 2, iy = (int)fy - ly * v.dim + v.dim / 2;   // 0 .. dim - 1
+    val = v.pool[(size_t)t * v.dim * v.dim + (size_t)ix * v.dim + iy];
     return true;
 }
 
