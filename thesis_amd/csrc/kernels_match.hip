@@ -302,7 +302,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     MSTAMP(2);
     // Neighbouring translation candidates along y are consecutive bits of one mask row, so one LDS read scores a whole
     // row of them: a work item is (rotation, x translation); its per-candidate sums are byte lanes of two registers.
-    const int n8 = ((nb + 7) / 8 + 3) & ~3, n4 = ((nb + 3) / 4 + 3) & ~3;       // padded with far-away beams
+    const int n4 = ((nb + 3) / 4 + 3) & ~3;                                      // padded with far-away beams
     const float gthf = (float)remainder(gth, 6.283185307179586);
     const int CW = match_crs_words(N);
     const int NC4 = N / M_COARSE;
@@ -311,27 +311,25 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     // coarse cells) and, through the byte lanes, for 8 y translations per LDS read; slices add their sums with atomics
     {
         const int MAXTX = 7;
-        const int NSC = max(1, MBLOCK / nr), G8 = n8 / 4, per = (G8 + NSC - 1) / NSC;
+        const int NSC = max(1, MBLOCK / nr), nb8 = (nb + 7) / 8, per = (nb8 + NSC - 1) / NSC;   // beams per slice
         for (int item = tid; item < nr * NSC; item += MBLOCK) {
             const int ir = item / NSC, sl = item % NSC;
             float sn, cs;
             __sincosf(gthf + (float)((double)(ir - a.n_coarse_rot) * M_COARSE * a.d0), &sn, &cs);
-            const int g_lo = sl * per, g_hi = min(G8, g_lo + per);
+            const int g_lo = sl * per, g_hi = min(nb8, g_lo + per);
             for (int g0 = 0; g0 < nty; g0 += 8)                         // up to 8 y translations per pass
             for (int t0 = 0; t0 < ntx; t0 += MAXTX)                     // up to MAXTX x translations per pass
-            for (int gg = g_lo; gg < g_hi; gg += 60) {                  // byte-lane sums stay below 256
+            for (int gg = g_lo; gg < g_hi; gg += 240) {                 // byte-lane sums stay below 256
                 const float ty0 = fy + (float)((g0 - max(kty, 0)) * M_COARSE);
                 uint32_t accA[MAXTX], accB[MAXTX];
 #pragma unroll
                 for (int t = 0; t < MAXTX; ++t) { accA[t] = 0; accB[t] = 0; }
-                const int ge = min(g_hi, gg + 60);
+                const int ge = min(g_hi, gg + 240);
                 for (int g = gg; g < ge; ++g) {
-                    const float4 bx4 = *reinterpret_cast<const float4*>(s.cx8 + 4 * g), by4 = *reinterpret_cast<const float4*>(s.cy8 + 4 * g);
-                    const float bxs[4] = {bx4.x, bx4.y, bx4.z, bx4.w}, bys[4] = {by4.x, by4.y, by4.z, by4.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int u0 = (int)floorf(cs * bxs[k] - sn * bys[k] + fx) + (t0 - max(ktx, 0)) * M_COARSE;
-                        const int cw0 = (int)floorf(sn * bxs[k] + cs * bys[k] + ty0) >> 2;   // candidate j looks at coarse column cw0 + j
+                    const float bxs = s.cx8[g], bys = s.cy8[g];
+                    {
+                        const int u0 = (int)floorf(cs * bxs - sn * bys + fx) + (t0 - max(ktx, 0)) * M_COARSE;
+                        const int cw0 = (int)floorf(sn * bxs + cs * bys + ty0) >> 2;         // candidate j looks at coarse column cw0 + j
                         const bool col_ok = cw0 >= 0 && cw0 + 7 < NC4;
                         const int sh = cw0 & 31, wi = cw0 >> 5;
                         const bool two = sh > 24 && wi + 1 < CW;
@@ -341,7 +339,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                             const bool in = col_ok && t0 + t < ntx && (unsigned)u < (unsigned)N;
                             const int i0 = in ? (u >> 2) * CW + wi : 0;
                             const uint32_t lo = in ? s.crs[i0] : 0u, hi = (in && two) ? s.crs[i0 + 1] : 0u;
-                            const uint32_t bits = ((lo >> sh) | (sh ? hi << (32 - sh) : 0u)) & 0xFFu;
+                            const uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh) & 0xFFu;   // funnel shift of hi:lo
                             accA[t] += ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
                             accB[t] += ((bits >> 4) * 0x00204081u) & 0x01010101u;
                         }
