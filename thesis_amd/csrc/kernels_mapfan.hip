@@ -40,6 +40,7 @@ static const int FEV = 5120;                   // ordered events
 static const int FMARK = 256;                  // chunks that met a flagged cell more than 32 steps before the ray's end
 static const int FLIST = 256;                  // deep buckets (17..64 events) / membership-scan cells per particle
 static const int MAXLEV = 20;                  // chunks per ray
+static const int FIX_SHIFT = 22;               // fixed-point bits of the walk's DDA (fix_slope)
 static const int BLK = 128;                    // cells per block of the flagged-cell directory
 // an 8-bit field seen with bits 5 and 6 set (>= 96 hits) -> the particle goes to the window kernel
 
@@ -90,7 +91,7 @@ __host__ __device__ inline FanGeom fan_geom(int B, int reach) {
     g.o_dummy = o; o += 256;
     g.o_bev = o;   o += FEV * 2;
     g.bytes = o;
-    g.ok = ncell >= 32768 && g.bytes + 1024 <= 160 * 1024 && reach + 1 <= CHUNK * MAXLEV && B <= 4095 && reach >= 3 &&
+    g.ok = ncell >= 32768 && g.bytes + 1024 <= 160 * 1024 && reach + 1 <= CHUNK * MAXLEV && B <= 4095 && reach >= 3 && 2LL * reach * reach < (1LL << FIX_SHIFT) &&
            (B + 64) * MAXLEV < 65536;
     return g;
 }
@@ -132,24 +133,33 @@ template <> struct Fld<true> {
     static const uint32_t FLAG = 0x8000u, MASK = 0xFFFFu, CNT = 0x7FFFu;
 };
 
+// Fixed-point DDA for the reference's Bresenham variant: minor(j) = floor((2*dmin*j + dmaj) / (2*dmaj)) (rbpf_math.h) equals
+// (fix_slope * j + 2^(FIX_SHIFT-1)) >> FIX_SHIFT with fix_slope = ceil(dmin * 2^FIX_SHIFT / dmaj): the accumulated
+// excess is below j / 2^FIX_SHIFT, while the exact value is either an integer or at least 1 / (2*dmaj) below the next
+// one - so the two floors agree as long as 2 * dmaj * j < 2^FIX_SHIFT (rays up to 1447 cells).
+__device__ __forceinline__ uint32_t fix_slope(int dmin, int dmaj) {
+    return dmaj ? (((uint32_t)dmin << FIX_SHIFT) + (uint32_t)dmaj - 1u) / (uint32_t)dmaj : 0u;
+}
+
 // One chunk of a ray whose index map is the identity from the start cell to the chunk's end: the field index advances
 // by constants.  cw = counter words (main window or the 16-bit block), c = field index of step jlo.  SAT: read the
 // field first and skip the add on an unflagged cell that already has `sat` hits (max(v + n*emp, vmin) is vmin for every
 // n >= sat; spares the serialised same-address atomics next to the sensor); skipped adds go to `sink` (a zero word).
 // guard accumulates f & (f << 1) of every 8-bit field seen: bit 6 set = some field was at >= 96.
 template <bool MINI, bool SAT>
-__device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* __restrict__ sink, int c, int dmajc, int dminc,
-                                           int D, int dmaj2, int dmin2, int jlo, int jhi, int n, uint32_t sat,
+__device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* __restrict__ sink, int cm, int dmajc, int dminc,
+                                           uint32_t facc, uint32_t fstep, int jlo, int jhi, int n, uint32_t sat,
                                            bool near_ok, uint32_t& hmask, uint32_t& guard) {
+    // cm = field index of (major step jlo, minor offset 0); the minor offset of step j is facc >> FIX_SHIFT (fixed-point
+    // DDA, exact: see fix_slope)
     typedef Fld<MINI> F;
     int j = jlo;
     for (; j + 3 <= jhi; j += 4) {
         int cc[4]; uint32_t h[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            cc[u] = c;
-            if (D >= 0) { c += dminc; D -= dmaj2; }
-            D += dmin2; c += dmajc;
+            cc[u] = cm + __mul24((int)(facc >> FIX_SHIFT), dminc);
+            cm += dmajc; facc += fstep;
         }
         uint32_t* ap[4]; uint32_t av[4];
         if (SAT) {
@@ -190,9 +200,8 @@ __device__ __forceinline__ void walk_ident(uint32_t* __restrict__ cw, uint32_t* 
         int cc[3]; uint32_t h[3]; uint32_t* ap[3]; uint32_t av[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            cc[u] = c;
-            if (D >= 0) { c += dminc; D -= dmaj2; }
-            D += dmin2; c += dmajc;
+            cc[u] = cm + __mul24((int)(facc >> FIX_SHIFT), dminc);
+            cm += dmajc; facc += fstep;
             if (j + u > jhi) cc[u] = cc[0];                                // dead step: a valid address, nothing added
         }
         if (SAT) {
@@ -563,8 +572,8 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             const int jlo = k * CHUNK, jhi = min(r.n - 1, jlo + CHUNK - 1);
             const int smaj = r.steep ? r.sy : r.sx, smin = r.steep ? r.sx : r.sy;
             const bool near_ok = info & RI_NEAR;
-            int m = k ? ray_minor_at(r, jlo) : 0;
-            int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;       // hybridmap.py:289-300 invariant
+            const uint32_t fstep = fix_slope(r.dmin, r.dmaj), facc = fstep * (uint32_t)jlo + (1u << (FIX_SHIFT - 1));
+            int m = (int)(facc >> FIX_SHIFT);                                      // minor offset of step jlo
             // is the index map the identity between the start cell and every cell of this chunk?
             bool ident = total_irreg == 0;
             if (!ident) {
@@ -576,22 +585,21 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             uint32_t hit = 0;                                                      // bit u: step jlo + u met a flagged cell
             uint32_t acc = 0;
             if (ident) {
-                const int dxj = r.steep ? smin * m : smaj * jlo, dyj = r.steep ? smaj * jlo : smin * m;   // offset of step jlo
                 if (k == 0) {
-                    const int c = (dxj + MINI_R) * MINI_W + (dyj + MINI_R);
-                    walk_ident<true, true>(mini, dummy + lane, c, smaj * (r.steep ? 1 : MINI_W), smin * (r.steep ? MINI_W : 1), D,
-                                           2 * r.dmaj, 2 * r.dmin, jlo, jhi, r.n, sat, near_ok, hit, acc);
+                    const int dmajc = smaj * (r.steep ? 1 : MINI_W), dminc = smin * (r.steep ? MINI_W : 1);
+                    walk_ident<true, true>(mini, dummy + lane, MINI_R * MINI_W + MINI_R + jlo * dmajc, dmajc, dminc, facc, fstep,
+                                           jlo, jhi, r.n, sat, near_ok, hit, acc);
                 } else {
-                    const int c = (wxc + dxj) * stride + (wyc + dyj);
+                    const int dmajc = smaj * (r.steep ? 1 : stride), dminc = smin * (r.steep ? stride : 1);
+                    const int cm = wxc * stride + wyc + jlo * dmajc;
                     if (k < 2)                                                       // wave-uniform: a level is whole waves
-                        walk_ident<false, true>(cnt, dummy + lane, c, smaj * (r.steep ? 1 : stride), smin * (r.steep ? stride : 1), D,
-                                                2 * r.dmaj, 2 * r.dmin, jlo, jhi, r.n, sat, near_ok, hit, acc);
+                        walk_ident<false, true>(cnt, dummy + lane, cm, dmajc, dminc, facc, fstep, jlo, jhi, r.n, sat, near_ok, hit, acc);
                     else
-                        walk_ident<false, false>(cnt, dummy + lane, c, smaj * (r.steep ? 1 : stride), smin * (r.steep ? stride : 1), D,
-                                                 2 * r.dmaj, 2 * r.dmin, jlo, jhi, r.n, sat, near_ok, hit, acc);
+                        walk_ident<false, false>(cnt, dummy + lane, cm, dmajc, dminc, facc, fstep, jlo, jhi, r.n, sat, near_ok, hit, acc);
                 }
             } else {
                 // general path: every step through the index map; the 16-bit block is chosen per cell
+                int D = 2 * r.dmin - r.dmaj + 2 * r.dmin * jlo - 2 * r.dmaj * m;   // hybridmap.py:289-300 invariant
                 const int m0 = r.steep ? y0 : x0, n0 = r.steep ? x0 : y0;
                 for (int j4 = jlo; j4 <= jhi; j4 += 4) {
                     uint32_t* wp[4]; int sh[4]; uint32_t fm[4]; uint32_t h[4]; bool live[4];
