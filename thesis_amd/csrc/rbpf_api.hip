@@ -146,7 +146,6 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     v.inv_quantum = fabs(inv - round(inv)) < 1e-9 ? round(inv) : 0.0;
     v.cc = cc;
     v.w_min_range = c.weight_min_range; v.w_max_range = c.weight_max_range;
-    v.items_cap = 0;
     v.reach = (int)(c.max_ray_m / c.cell_size) + 3;
 
     // ---- global-index LUT (hybridmap.py:123,136 + gridmap.py:93) -------------------------------
@@ -216,7 +215,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
                 for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) HIP_TRY(h, hipEventCreateWithFlags(&rings[r]->ev[i], hipEventDisableTiming));
             }
         }
-        ALLOC(h, v.upd_pose, 3 * P); ALLOC(h, v.n_items, 2);
+        ALLOC(h, v.upd_pose, 3 * P);
         ALLOC(h, v.stats, 16); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
         ALLOC(h, h->d_did_early, 1);
@@ -243,7 +242,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemset(v.pool, 0, (size_t)v.pool_tiles * cells));
         HIP_TRY(h, hipMemset(v.px, 0, P * 8)); HIP_TRY(h, hipMemset(v.py, 0, P * 8)); HIP_TRY(h, hipMemset(v.pth, 0, P * 8));
         HIP_TRY(h, hipMemset(v.cov, 0, 9 * P * 8));
-        HIP_TRY(h, hipMemset(v.stats, 0, 128)); HIP_TRY(h, hipMemset(v.err, 0, 4)); HIP_TRY(h, hipMemset(v.n_items, 0, 8));
+        HIP_TRY(h, hipMemset(v.stats, 0, 128)); HIP_TRY(h, hipMemset(v.err, 0, 4));
         // robot.py:20-28 / hybridmap.py:70: weight 1.0, one empty tile centred (0,0) per particle
         std::vector<double> w(P, 1.0);
         HIP_TRY(h, hipMemcpy(v.weight, w.data(), P * 8, hipMemcpyHostToDevice));
@@ -258,8 +257,6 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemcpy(v.free_stack, fs.data(), (size_t)v.pool_tiles * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(v.free_top, &top, 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(v.tile_bbox, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
-        h->h_pinned_bytes = std::max<size_t>((size_t)c.max_beams * 64, 1 << 16);
-        HIP_TRY(h, hipHostMalloc(&h->h_pinned, h->h_pinned_bytes, hipHostMallocDefault));
         // the ray-cast kernel needs more than the default 64 KiB of dynamic LDS
         return RBPF_OK;
     };
@@ -280,7 +277,6 @@ int rbpf_destroy(rbpf_handle* h) {
     if (h->d_gidx) hipFree(h->d_gidx);
     if (h->d_i32) hipFree(h->d_i32);
     if (h->d_jobs) hipFree(h->d_jobs);
-    if (h->h_pinned) hipHostFree(h->h_pinned);
     if (h->ev_weights) hipEventDestroy(h->ev_weights);
     if (h->ev_early) hipEventDestroy(h->ev_early);
     if (h->h_early) hipHostFree(h->h_early);

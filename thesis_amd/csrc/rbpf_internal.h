@@ -22,7 +22,6 @@ struct DevView {
     // configuration
     int P, K, B, dim, R, L;            // L = 2R+1 lattice edge
     int pool_tiles;
-    int items_cap;                     // window work items per particle (capacity)
     int reach;                         // longest ray in cells (+ margin)
     double cs, tile_len;
     double quantum, inv_quantum;       // inv_quantum = round(1/quantum) when exact, else 0
@@ -52,10 +51,6 @@ struct DevView {
     float *asel_x, *asel_y; int n_asel;  // beams with BF_MATCH_ADJ, compacted
     // per-update scratch
     double*  upd_pose;                 // [3][P] poses used by the current map update
-    int32_t* ray_end;                  // [P][B] packed (dx & 0xFFFF) | (dy << 16) relative to the start cell
-    int32_t* ray_start;                // [P][2] start cell, or INT_MIN when the particle is skipped
-    int32_t* items;                    // [P*MAX_ITEMS][4] particle, pool tile, wx0 | wy0<<16, lat x | lat y<<16
-    int32_t* n_items;                  // [1]
     int32_t* mu_fallback;              // [P] 1 = the whole-fan map update gave the particle back to the window kernel
     int mu_mode;                       // 0 = whole-fan kernel when the layout allows it, 1 = 128x128 windows only
     unsigned long long* stats;         // [8] device counters
@@ -87,7 +82,6 @@ struct rbpf_handle {
     std::vector<uint32_t> h_lut;
     std::vector<void*> allocs;
     // host staging
-    void* h_pinned = nullptr; size_t h_pinned_bytes = 0;
     // pinned staging rings for the per-step uploads (scan block, previous scan): a slot is reused only after the copy
     // that read it has completed (its event), so uploading never drains the stream
     struct PinnedRing {
