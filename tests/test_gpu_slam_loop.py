@@ -81,3 +81,44 @@ def test_checkpoint_continues_bit_identically(tmp_path):
         for (_, ca), (_, cb) in zip(ta, tb):
             assert np.array_equal(ca, cb)
     a.close(); b.close()
+
+
+def test_long_run_fan_kernel_equals_window_kernel(monkeypatch):
+    """120 steps of the full pipeline (matcher, proposal, map update, resample) on two engines that differ only in the
+    map-update kernel (whole-fan vs 128x128 windows): states after every step and all maps at the end are identical.
+    The fan kernel's rare paths (fallback to windows, deep buckets, NaN branch) all leave the result unchanged."""
+    from thesis_amd import engine
+    from thesis_amd.datasets import synthetic
+    P, B, T = 192, 1081, 120
+    ang, ranges, odo, _ = synthetic.make_log(T, B, period=0.7)
+    monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
+    a = engine.ParticleEngine(P, max_beams=B, pool_tiles=4 * P, seed=5)
+    monkeypatch.setenv("RBPF_MAP_KERNEL", "window")
+    b = engine.ParticleEngine(P, max_beams=B, pool_tiles=4 * P, seed=5)
+    urng = np.random.Generator(np.random.PCG64(12))
+    for e in (a, b):
+        e.set_scan(ranges[0], ang)
+        e.map_update(np.zeros((P, 3)))
+        e.refresh_last_scan(0)
+    for k in range(T):
+        u = float(urng.random())
+        adj = not (k % 5 < 2)
+        res = []
+        for e in (a, b):
+            e.imu_update("velocity", odo[k], 7000.0)
+            e.set_scan(ranges[k + 1], ang)
+            e.scan_update(adj=adj)
+            res.append(e.resample(u))
+            if k % 5 == 0:
+                e.refresh_last_scan(0)
+        assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]), f"ancestors differ at step {k}"
+        if k % 10 == 9:
+            assert np.array_equal(a.poses(), b.poses()) and np.array_equal(a.weights(), b.weights()), f"state differs at step {k}"
+    ca, cb = a.counters(), b.counters()
+    assert cb["window_fallbacks"] == 0 and ca["ray_cells_visited"] == cb["ray_cells_visited"] and ca["cells_written"] == cb["cells_written"]
+    for p in range(0, P, 7):
+        ta, tb = a.tiles(p), b.tiles(p)
+        assert [c for c, _ in ta] == [c for c, _ in tb]
+        for (_, x), (_, y) in zip(ta, tb):
+            assert np.array_equal(x, y)
+    a.close(); b.close()
