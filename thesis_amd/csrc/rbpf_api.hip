@@ -222,6 +222,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_early, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
         {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle (tests, comparisons)
             const char* mk = getenv("RBPF_MAP_KERNEL");
             v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
@@ -278,6 +279,8 @@ int rbpf_destroy(rbpf_handle* h) {
     if (h->d_i32) hipFree(h->d_i32);
     if (h->d_jobs) hipFree(h->d_jobs);
     if (h->ev_weights) hipEventDestroy(h->ev_weights);
+    if (h->ev_jobs) hipEventDestroy(h->ev_jobs);
+    if (h->h_jobs) hipHostFree(h->h_jobs);
     if (h->ev_early) hipEventDestroy(h->ev_early);
     if (h->h_early) hipHostFree(h->h_early);
     for (rbpf_handle::PinnedRing* r : {&h->ring_scan, &h->ring_last, &h->ring_idx}) {
@@ -749,6 +752,24 @@ int64_t rbpf_packed_particle_bytes(rbpf_handle* h) {
 }
 
 // meta record of one particle: [0] tiles, [1] payload bytes / 16, then per lattice position (has, x0, x1, ya, yb, offset / 16)
+// job lists of the pack / unpack kernels go through one pinned buffer: the copy is asynchronous and the std::vector may
+// die on return; the event tells when the buffer may be overwritten
+static int stage_jobs(rbpf_handle* h, const void* src, size_t bytes) {
+    if (h->h_jobs_used) HIP_TRY(h, hipEventSynchronize(h->ev_jobs));
+    if (bytes > h->h_jobs_bytes) {
+        if (h->h_jobs) HIP_TRY(h, hipHostFree(h->h_jobs));
+        h->h_jobs_bytes = std::max<size_t>(bytes * 2, 1 << 16);
+        HIP_TRY(h, hipHostMalloc(&h->h_jobs, h->h_jobs_bytes, hipHostMallocDefault));
+    }
+    memcpy(h->h_jobs, src, bytes);
+    int rc = scratch(h, &h->d_jobs, &h->d_jobs_cap, bytes);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_jobs, h->stream));
+    h->h_jobs_used = true;
+    return RBPF_OK;
+}
+
 int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_buf, int64_t cap_bytes,
                         int32_t* meta_out, int64_t* bytes_out) {
     if (!h || n < 0 || !bytes_out || (n > 0 && (!local_idx || !d_buf || !meta_out))) return RBPF_EINVAL;
@@ -790,14 +811,12 @@ int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, voi
         m[0] = nt; m[1] = (int32_t)((off - start) / 16);
     }
     if (off > cap_bytes) return fail(h, RBPF_ENOMEM, "pack buffer too small");
-    rc = scratch(h, &h->d_jobs, &h->d_jobs_cap, jobs.size() * sizeof(PackJobHost));
+    rc = stage_jobs(h, jobs.data(), jobs.size() * sizeof(PackJobHost));
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(PackJobHost), hipMemcpyHostToDevice, h->stream));
     launch_pack(v, h->d_jobs, (int)jobs.size(), d_buf, h->stream);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     *bytes_out = off;
-    return RBPF_OK;
+    return RBPF_OK;                                     // the buffer is filled in stream order: send it on the handle's stream
 }
 
 // installs n received particles at the given local indices (after rbpf_apply_resample_local); weight <- 1.0 (main.py:77-78)
@@ -818,12 +837,11 @@ int rbpf_unpack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, c
         }
         off += (int64_t)m[1] * 16;
     }
-    int rc = scratch(h, &h->d_jobs, &h->d_jobs_cap, jobs.size() * sizeof(UnpackJobHost));
+    int rc = stage_jobs(h, jobs.data(), jobs.size() * sizeof(UnpackJobHost));
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(UnpackJobHost), hipMemcpyHostToDevice, h->stream));
     launch_unpack(v, h->rs, h->d_jobs, (int)jobs.size(), d_buf, h->stream);
     HIP_TRY(h, hipGetLastError());
-    return check_device_error(h);
+    return RBPF_OK;                                     // no host synchronisation; device errors surface at the next check
 }
 
 // ---- state access -----------------------------------------------------------------------------------------

@@ -93,6 +93,7 @@ struct rbpf_handle {
     PinnedRing ring_scan, ring_last, ring_idx;
     hipEvent_t ev_weights = nullptr; bool ev_weights_valid = false;   // recorded after the weighting kernel of rbpf_scan_update_begin
     int32_t* d_did_early = nullptr; bool scan_begun = false;
+    void* h_jobs = nullptr; size_t h_jobs_bytes = 0; hipEvent_t ev_jobs = nullptr; bool h_jobs_used = false;   // pinned job-list staging
     hipEvent_t ev_early = nullptr; void* h_early = nullptr; size_t h_early_bytes = 0; int early_n = 0;   // early resample read-back
     unsigned char* d_scan = nullptr; size_t scan_bytes = 0;   // device scan block, same layout as a ring_scan slot
     // scratch device buffers for test entries
