@@ -506,7 +506,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void sources_to_T_kernel(int P, const
 // (a stage reads what the previous one wrote to global memory: same CU, __syncthreads() orders it), which saves
 // three kernel launches and their dispatch gaps per resample.
 enum { RS_PLAN = 1, RS_SRC2T = 2, RS_EXPAND = 4, RS_PAIR = 8, RS_GATHER = 16 };
-static const int RS_FUSE_MAX = 16384;
+static const int RS_FUSE_MAX = 4096;        // beyond this the single workgroup costs more than the launches it saves
 struct FusedArgs { int stages; ResampleArgs ra; int32_t* idx; PairArgs pa; GatherArgs ga; };
 __global__ __launch_bounds__(PLAN_THREADS) void resample_fused_kernel(FusedArgs f) {
     const int tid = threadIdx.x;
