@@ -233,48 +233,52 @@ struct CopyArgs {
     int32_t* pending_free; int32_t* n_pending;
 };
 
+template <int NT>
 __device__ __forceinline__ void copy_rows(int8_t* dst, const int8_t* src, int dim, int x0, int x1, int y0, int y1,
                                           int tid) {
     // rows x0..x1, columns rounded out to 16-byte groups; src == nullptr zero-fills; four loads in flight per thread
     const int ya = y0 & ~15, yb = min((y1 | 15) + 1, dim);
     const int per_row = (yb - ya) / 16;
     const int n = (x1 - x0 + 1) * per_row;
-    for (int q0 = tid; q0 < n; q0 += 4 * BLOCK) {
+    for (int q0 = tid; q0 < n; q0 += 4 * NT) {
         uint4 val[4]; size_t off[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int q = q0 + k * BLOCK;
+            const int q = q0 + k * NT;
             const int qq = q < n ? q : q0;
             off[k] = (size_t)(x0 + qq / per_row) * dim + ya + (qq % per_row) * 16;
             val[k] = src ? *reinterpret_cast<const uint4*>(src + off[k]) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (q0 + k * BLOCK < n) *reinterpret_cast<uint4*>(dst + off[k]) = val[k];
+            if (q0 + k * NT < n) *reinterpret_cast<uint4*>(dst + off[k]) = val[k];
     }
 }
 
 // occupancy-bitmask words of rows x0..x1, columns y0..y1 of a tile; src == nullptr zero-fills; eight loads in flight per thread
+template <int NT>
 __device__ __forceinline__ void copy_occ_rows(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int ow, int x0, int x1,
                                               int y0, int y1, int tid) {
     const int wa = y0 >> 5, per_row = (y1 >> 5) - wa + 1;
     const int n = (x1 - x0 + 1) * per_row;
-    for (int q0 = tid; q0 < n; q0 += 8 * BLOCK) {
+    for (int q0 = tid; q0 < n; q0 += 8 * NT) {
         uint32_t val[8]; size_t off[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int q = q0 + k * BLOCK;
+            const int q = q0 + k * NT;
             const int qq = q < n ? q : q0;
             off[k] = (size_t)(x0 + qq / per_row) * ow + wa + qq % per_row;
             val[k] = src ? src[off[k]] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (q0 + k * BLOCK < n) dst[off[k]] = val[k];
+            if (q0 + k * NT < n) dst[off[k]] = val[k];
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
+// 1024 threads per job: a job is one tile box (~100 KB), its duration is set by the copies one workgroup keeps in flight
+static const int COPY_BLOCK = 1024;
+__global__ __launch_bounds__(COPY_BLOCK) void resample_copy_kernel(CopyArgs a) {
     __shared__ int s_item, s_tile, s_ts[49], s_td[49];
     const DevView& v = a.v;
     const int tid = threadIdx.x;
@@ -311,8 +315,8 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
             // copy the union of both written regions (outside its box a tile is zero)
             int x0 = min(sb[0], db[0]), x1 = max(sb[1], db[1]), y0 = min(sb[2], db[2]), y1 = max(sb[3], db[3]);
             if (x0 <= x1 && y0 <= y1) {
-                copy_rows(v.pool + (size_t)td * cells, v.pool + (size_t)ts * cells, v.dim, x0, x1, y0, y1, tid);
-                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, v.occ + (size_t)ts * v.dim * v.ow, v.ow, x0, x1, y0, y1, tid);
+                copy_rows<COPY_BLOCK>(v.pool + (size_t)td * cells, v.pool + (size_t)ts * cells, v.dim, x0, x1, y0, y1, tid);
+                copy_occ_rows<COPY_BLOCK>(v.occ + (size_t)td * v.dim * v.ow, v.occ + (size_t)ts * v.dim * v.ow, v.ow, x0, x1, y0, y1, tid);
                 if (tid == 0) {
                     const int ya = y0 & ~15, yb = min((y1 | 15) + 1, v.dim);
                     atomicAdd(&v.stats[ST_COPY_BYTES], 2ull * (unsigned long long)(x1 - x0 + 1) * (yb - ya));
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(BLOCK) void resample_copy_kernel(CopyArgs a) {
             for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
             if (db[0] <= db[1] && db[2] <= db[3])
             {
-                copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
-                copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
+                copy_rows<COPY_BLOCK>(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+                copy_occ_rows<COPY_BLOCK>(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
             }
             if (tid == 0) {
                 v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1;
@@ -445,8 +449,8 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJo
         int db[4];
         for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
         if (db[0] <= db[1] && db[2] <= db[3]) {
-            copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
-            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
+            copy_rows<BLOCK>(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+            copy_occ_rows<BLOCK>(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
         }
         if (tid == 0) {
             v.tile_bbox[4 * td + 0] = INT_MAX; v.tile_bbox[4 * td + 1] = -1; v.tile_bbox[4 * td + 2] = INT_MAX; v.tile_bbox[4 * td + 3] = -1;
@@ -468,8 +472,8 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(DevView v, const UnpackJo
         int db[4];
         for (int k = 0; k < 4; ++k) db[k] = v.tile_bbox[4 * td + k];
         if (db[0] <= db[1] && db[2] <= db[3]) {
-            copy_rows(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
-            copy_occ_rows(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
+            copy_rows<BLOCK>(v.pool + (size_t)td * cells, nullptr, v.dim, db[0], db[1], db[2], db[3], tid);
+            copy_occ_rows<BLOCK>(v.occ + (size_t)td * v.dim * v.ow, nullptr, v.ow, db[0], db[1], db[2], db[3], tid);
         }
         __syncthreads();
     }
@@ -562,7 +566,7 @@ void launch_resample_local(const DevView& v, const ResampleBuffers& b, const dou
                 GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2}};
     hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
-    hipLaunchKernelGGL(resample_copy_kernel, dim3(1024), dim3(BLOCK), 0, s, ca);
+    hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
 
@@ -578,7 +582,7 @@ void launch_resample_apply_sources(const DevView& v, const ResampleBuffers& b, h
                 GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2}};
     hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
-    hipLaunchKernelGGL(resample_copy_kernel, dim3(1024), dim3(BLOCK), 0, s, ca);
+    hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
 
@@ -589,7 +593,7 @@ void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream
                   b.px2, b.py2, b.pth2, b.cov2, b.w2};
     hipLaunchKernelGGL(resample_gather_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, ga);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
-    hipLaunchKernelGGL(resample_copy_kernel, dim3(1024), dim3(BLOCK), 0, s, ca);
+    hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
 
