@@ -72,13 +72,15 @@ __device__ void resample_plan_stage(const ResampleArgs& a) {
     // main.py:50  max(weights) - min(weights) > 200
     double mx = -INFINITY, mn = INFINITY;
     for (int i = i0; i < i1; ++i) { double w = a.w[i]; mx = fmax(mx, w); mn = fmin(mn, w); }
-    s_red[tid] = mx; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
-    if (tid == 0) s_max = s_red[0];
+    const int lane = tid & 63, wave = tid >> 6, nw = nt / 64;
+    for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); mn = fmin(mn, __shfl_xor(mn, o, 64)); }
+    if (lane == 0) { s_red[wave] = mx; s_red[nw + wave] = mn; }
     __syncthreads();
-    s_red[tid] = mn; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmin(s_red[tid], s_red[tid + s]); __syncthreads(); }
-    if (tid == 0) s_min = s_red[0];
+    if (tid == 0) {
+        double a = s_red[0], b = s_red[nw];
+        for (int w = 1; w < nw; ++w) { a = fmax(a, s_red[w]); b = fmin(b, s_red[nw + w]); }
+        s_max = a; s_min = b;
+    }
     __syncthreads();
     const bool go = (s_max - s_min) > a.spread;
     if (!go) {
@@ -89,9 +91,10 @@ __device__ void resample_plan_stage(const ResampleArgs& a) {
     // main.py:53-55: -inf -> 0, then every non-zero weight += |min| when the minimum is negative
     double mn2 = INFINITY;
     for (int i = i0; i < i1; ++i) { double w = a.w[i]; if (w == -INFINITY) w = 0.0; mn2 = fmin(mn2, w); }
-    s_red[tid] = mn2; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmin(s_red[tid], s_red[tid + s]); __syncthreads(); }
-    if (tid == 0) s_min2 = s_red[0];
+    for (int o = 32; o > 0; o >>= 1) mn2 = fmin(mn2, __shfl_xor(mn2, o, 64));
+    if (lane == 0) s_red[wave] = mn2;
+    __syncthreads();
+    if (tid == 0) { double b = s_red[0]; for (int w = 1; w < nw; ++w) b = fmin(b, s_red[w]); s_min2 = b; }
     __syncthreads();
     const double shift = s_min2 < 0 ? fabs(s_min2) : 0.0;
     auto adj = [&](double w) -> dd {
@@ -100,20 +103,25 @@ __device__ void resample_plan_stage(const ResampleArgs& a) {
         return dd{w, 0.0};
     };
 
-    // chunk totals, then an inclusive Hillis-Steele scan over the 1024 totals
+    // chunk totals, then an inclusive scan over the 1024 totals: shuffles inside a wave, the 16 wave totals through LDS
     dd tot = {0.0, 0.0};
     for (int i = i0; i < i1; ++i) tot = dd_add(tot, adj(a.w[i]));
-    s_hi[tid] = tot.hi; s_lo[tid] = tot.lo;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {
-        dd v = {s_hi[tid], s_lo[tid]};
-        if (tid >= off) v = dd_add(dd{s_hi[tid - off], s_lo[tid - off]}, v);
-        __syncthreads();
-        s_hi[tid] = v.hi; s_lo[tid] = v.lo;
-        __syncthreads();
+    dd incl = tot;
+    for (int off = 1; off < 64; off <<= 1) {
+        const dd n = {__shfl_up(incl.hi, off, 64), __shfl_up(incl.lo, off, 64)};
+        if (lane >= off) incl = dd_add(n, incl);
     }
-    const dd total = {s_hi[nt - 1], s_lo[nt - 1]};
-    dd run = tid > 0 ? dd{s_hi[tid - 1], s_lo[tid - 1]} : dd{0.0, 0.0};
+    if (lane == 63) { s_hi[wave] = incl.hi; s_lo[wave] = incl.lo; }
+    __syncthreads();
+    dd wbase = {0.0, 0.0}, total = {0.0, 0.0};
+    for (int w = 0; w < nw; ++w) {
+        const dd x = {s_hi[w], s_lo[w]};
+        if (w < wave) wbase = dd_add(wbase, x);
+        total = dd_add(total, x);
+    }
+    dd prev = {__shfl_up(incl.hi, 1, 64), __shfl_up(incl.lo, 1, 64)};
+    if (lane == 0) prev = dd{0.0, 0.0};
+    dd run = dd_add(wbase, prev);                            // sum of everything before this thread's chunk
     const dd slice = dd_div_d(total, (double)a.P);            // main.py:57
     const dd start = dd_mul_d(slice, a.u);                    // main.py:59
     bool bad = !(slice.hi > 0) || !isfinite(slice.hi);
@@ -152,18 +160,18 @@ struct PairArgs {
     int32_t* err;
 };
 
+// exclusive prefix sum over the 1024 threads: shuffles inside a wave, 16 wave totals through LDS (two barriers)
 __device__ int block_exclusive_scan_1024(int val, int* s_buf, int tid, int& total) {
-    s_buf[tid] = val;
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = val;
+    for (int off = 1; off < 64; off <<= 1) { int n = __shfl_up(incl, off, 64); if (lane >= off) incl += n; }
+    __syncthreads();                                     // s_buf may still be read from a previous call
+    if (lane == 63) s_buf[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < PLAN_THREADS; off <<= 1) {
-        int v = s_buf[tid];
-        if (tid >= off) v += s_buf[tid - off];
-        __syncthreads();
-        s_buf[tid] = v;
-        __syncthreads();
-    }
-    total = s_buf[PLAN_THREADS - 1];
-    return s_buf[tid] - val;
+    int base = 0, tot = 0;
+    for (int w = 0; w < PLAN_THREADS / 64; ++w) { const int x = s_buf[w]; if (w < wave) base += x; tot += x; }
+    total = tot;
+    return base + incl - val;
 }
 
 __device__ void resample_pair_stage(const PairArgs& a) {
