@@ -14,8 +14,8 @@
  *     available from rbpf_last_error();
  *   - the caller owns every host buffer passed in or out (C-contiguous, float64 / int32 /
  *     int8); the library owns all device memory behind the opaque handle; no pointer is
- *     retained after a call returns, except device pointers handed over explicitly with
- *     rbpf_export_weights()/rbpf_resample_global(), which are used only during that call;
+ *     retained after a call returns; device pointers handed over explicitly (the rbpf_export_* /
+ *     rbpf_resample_indices_global* / rbpf_pack_* calls) are used in stream order by the work that call queues;
  *   - calls on one handle are not re-entrant; one HIP stream per handle (rbpf_set_stream);
  *   - a soft scan-matcher failure is not an error: it is reported per particle as NaN
  *     covariance and the engine takes the reference's fallback branch (robot.py:73-78).
@@ -82,7 +82,8 @@ typedef struct rbpf_counters {
     uint64_t scan_updates;        /* rbpf_scan_update/rbpf_map_update calls                       */
     uint64_t ray_cells_visited;   /* sum of Bresenham points over all rays                        */
     uint64_t cells_written;       /* unique cells written per update, summed (|W| over particles) */
-    uint64_t cells_gathered;      /* reserved                                                     */
+    uint64_t cells_gathered;      /* diagnostic: four 16-bit tallies of whole-fan fallback reasons
+                                     (geometry, walk tables / 8-bit guard, events, replay lists)  */
     uint64_t tiles_in_use;        /* tiles allocated from the pool (current)                      */
     uint64_t resample_copies;     /* tile copies made by resampling                               */
     uint64_t bytes_copied;        /* bytes moved by those copies (read + write)                   */
@@ -90,8 +91,8 @@ typedef struct rbpf_counters {
     double   ms_weight;           /* ... of the last weighting kernel                             */
     double   ms_match;            /* ... of the last scan-match kernels                           */
     double   ms_resample;         /* ... of the last resample (plan + copies)                     */
-    uint64_t slow_cells;          /* flagged cells that overflowed their ordered-event bucket     */
-    uint64_t reserved[7];
+    uint64_t slow_cells;          /* flagged cells replayed by the exact membership scan          */
+    uint64_t reserved[7];         /* phase cycle sums of a -DRBPF_STAMPS diagnostic build, else 0 */
     uint64_t window_fallbacks;    /* particles the whole-fan map update handed to the 128x128-window kernel */
 } rbpf_counters;
 
