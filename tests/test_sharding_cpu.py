@@ -136,7 +136,7 @@ def _worker(rank, world, p_local, port, rounds, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,p_local", [(2, 8), (2, 33)])
+@pytest.mark.parametrize("world,p_local", [(2, 8), (2, 33), (4, 12), (8, 5)])
 def test_sharded_resample_gloo_matches_single_process(world, p_local):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
