@@ -310,6 +310,9 @@ class ShardedResampler:
         ends = np.cumsum(n_out)
         b_out = [int(meta_all[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_out, ends)]
         metas, payloads = [meta_all], [pay_all]
+        # the departing particles are packed (stream order): the local part - slot pairing, state permutation, tile
+        # copies of duplicated ancestors - can run now, while the host exchanges the metadata
+        sh.apply_local(plan.new_src[r], plan.new_gid[r])
         n_in = [len(plan.send[q][r]) for q in range(self.world)]
         if sum(n_out) + sum(n_in) > 0 or self.world > 1:
             dev = payloads[0].device
@@ -324,7 +327,6 @@ class ShardedResampler:
             pay_recv = self._all_to_all(pay_send, b_out, b_in, torch.uint8)
         else:
             meta_in, pay_recv = np.zeros((0, W), dtype=np.int32), sh.empty_payload(0)
-        sh.apply_local(plan.new_src[r], plan.new_gid[r])
         arrivals = np.nonzero(plan.new_src[r] < 0)[0].astype(np.int32)
         sh.unpack(arrivals, meta_in, pay_recv)
         self._book(plan)
