@@ -122,3 +122,37 @@ def test_builtin_matcher_failure_takes_nan_branch():
     (_, cells), = e.tiles(0)
     assert np.count_nonzero(cells) > 1000
     e.close()
+
+
+def test_field_staging_fast_path_equals_bit_by_bit(monkeypatch):
+    """The matcher stages the particle's own map as funnel-shifted occupancy words plus the 'one cell lower' columns
+    of the reference's index formula; RBPF_MATCH_STAGE=slow reads every bit through the index map instead.  Both
+    must give the same match (pose, covariance, score) for particles on the irregular negative side of the map and
+    next to a tile edge."""
+    from thesis_amd import engine
+    from thesis_amd.datasets import synthetic
+    B = 1081
+    ang = synthetic.beam_angles(B)
+    rng = np.random.Generator(np.random.PCG64(4))
+    poses = np.array([[-11.0, -12.5, 0.3], [-3.0, -9.9, -1.2], [18.2, -18.7, 2.0], [0.4, 0.3, 0.1], [-15.5, 3.0, 1.0], [19.4, 19.1, -0.6]])
+    P = len(poses)
+    scans = [5.0 + 2.0 * np.sin(3 * ang) + rng.normal(0, 0.01, B), 4.0 + 2.5 * np.cos(5 * ang) + rng.normal(0, 0.01, B)]
+    outs = []
+    for mode in ("fast", "slow"):
+        if mode == "slow":
+            monkeypatch.setenv("RBPF_MATCH_STAGE", "slow")
+        else:
+            monkeypatch.delenv("RBPF_MATCH_STAGE", raising=False)
+        e = engine.ParticleEngine(P, max_beams=B, pool_tiles=64, seed=3)
+        e.set_state(poses=poses)
+        e.set_scan(scans[0], ang)
+        e.map_update(poses)
+        e.set_scan(scans[1], ang)
+        e.map_update(poses)
+        e.set_state(poses=poses + [0.08, -0.05, 0.02], covs=np.diag([4e-5, 4e-5, 1e-5]))
+        e.set_scan(scans[1], ang)
+        e.scan_update(adj=False)
+        outs.append((e.poses(), e.covs(), e.weights()))
+        e.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)

@@ -153,7 +153,9 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                 e = (int16_t)((lut_lat(ey) << 12) | lut_cidx(ey));
                 // the reference's float index formula is the plain cell arithmetic except at isolated
                 // columns: those are this word's defect bits
-                if (lut_cidx(ey) != gyi - (lut_lat(ey) - v.R) * v.dim + v.dim / 2) atomicOr(&s_def[(i >> 5) & 31], 1u << (i & 31));
+                const int dev_ = lut_cidx(ey) - (gyi - (lut_lat(ey) - v.R) * v.dim + v.dim / 2);
+                if (dev_ == -1) atomicOr(&s_def[(i >> 5) & 31], 1u << (i & 31));        // the only deviation the formula produces
+                else if (dev_ != 0) atomicOr(&s_slowg, 1u << ((i >> 5) & 31));
                 const int g0 = gyi - (i & 31);                  // the word's first column: must be the same tile
                 if ((i & 31) && !(lut_valid_g(v, g0) && lut_lat(lut_at(v, g0)) == lut_lat(ey))) atomicOr(&s_slowg, 1u << ((i >> 5) & 31));
             } else atomicOr(&s_slowg, 1u << ((i >> 5) & 31));
@@ -166,12 +168,13 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         MSTAMP(6);
         // One region word (32 columns of one row) per lane.  A wave takes 16 rows x 4 adjacent words, so that the words
         // with many defect columns meet in few waves and the loads of a row stay contiguous.
+        const int SW = 8;                                       // region words per lane and pass (loads in flight)
         const int WP = (W + 3) & ~3, GT = WP / 4;
-        const unsigned slowg = (a.ds != 1 || W > 32) ? 0xFFFFFFFFu : s_slowg;
-        for (int q0 = tid; q0 < N * WP; q0 += 4 * MBLOCK) {
-            uint32_t lo[4], hi[4], hi2[4]; int sh[4], c0r[4], uu[4], ww[4]; bool fast[4];
+        const unsigned slowg = (a.ds != 1 || W > 32 || v.match_stage_slow) ? 0xFFFFFFFFu : s_slowg;
+        for (int q0 = tid; q0 < N * WP; q0 += SW * MBLOCK) {
+            uint32_t lo[SW], hi[SW], hi2[SW]; int sh[SW], c0r[SW], uu[SW], ww[SW]; bool fast[SW];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                       // issue the mask loads of four words first
+            for (int k = 0; k < SW; ++k) {                      // issue the mask loads of SW words first
                 const int q = q0 + k * MBLOCK;
                 const int blk = q >> 6, l = q & 63;
                 const int u = (blk / GT) * 16 + (l & 15), wv = (blk % GT) * 4 + (l >> 4);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                 sh[k] = (cy >> 5) << 5;                         // first storage column of the loaded window
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SW; ++k) {
                 if (ww[k] < 0) continue;
                 const int u = uu[k], wv = ww[k];
                 uint32_t bits;
@@ -202,11 +205,11 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                     const int sft = c0r[k] - sh[k];                                          // 0..32
                     const unsigned long long w01 = ((unsigned long long)hi[k] << 32) | lo[k], w12 = ((unsigned long long)hi2[k] << 32) | hi[k];
                     bits = sft < 32 ? (uint32_t)(w01 >> sft) : (uint32_t)(w12 >> (sft - 32));
-                    for (uint32_t d = s_def[wv]; d; d &= d - 1) {
-                        const int b = __ffs(d) - 1;
-                        const int pcol = (colmap[wv * 32 + b] & 0xFFF) - sh[k];              // 0..95
-                        const uint32_t wsel = pcol < 32 ? lo[k] : pcol < 64 ? hi[k] : hi2[k];
-                        bits = (bits & ~(1u << b)) | (((wsel >> (pcol & 31)) & 1u) << b);
+                    const uint32_t d = s_def[wv];                                            // columns stored one cell lower
+                    if (d) {
+                        const int s1 = sft - 1;
+                        const uint32_t below = s1 < 0 ? bits << 1 : s1 < 32 ? (uint32_t)(w01 >> s1) : (uint32_t)(w12 >> (s1 - 32));
+                        bits = (bits & ~d) | (below & d);
                     }
                 } else {                                          // tile edge, unmapped column or coarser matcher cell: bit by bit
                     bits = 0;

@@ -226,6 +226,8 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle (tests, comparisons)
             const char* mk = getenv("RBPF_MAP_KERNEL");
             v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
+            const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
+            v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
         }
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
         if (raycast_lds_bytes(c.max_beams, v.reach) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");

@@ -53,6 +53,7 @@ struct DevView {
     double*  upd_pose;                 // [3][P] poses used by the current map update
     int32_t* mu_fallback;              // [P] 1 = the whole-fan map update gave the particle back to the window kernel
     int mu_mode;                       // 0 = whole-fan kernel when the layout allows it, 1 = 128x128 windows only
+    int match_stage_slow;              // 1 = the matcher stages its field bit by bit (RBPF_MATCH_STAGE=slow; the check of the fast path)
     unsigned long long* stats;         // [8] device counters
     int32_t* err;                      // [1] sticky device error code
 };
