@@ -132,9 +132,10 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * v.L * v.L;
         for (int i = tid; i < v.L * v.L; i += MBLOCK) s_tab[i] = tab[i];
     }
-    for (int i = tid; i < N * W; i += MBLOCK) { s.occ[i] = 0; s.dil[i] = 0; }
+    // the occupancy words are OR-ed into when rasterised from points (mode 1); every other word of the three fields is
+    // written before it is read
+    if (a.mode != 0) for (int i = tid; i < N * W; i += MBLOCK) s.occ[i] = 0;
     if (tid < 32) s_def[tid] = 0;
-    for (int i = tid; i < (N / M_COARSE) * match_crs_words(N); i += MBLOCK) s.crs[i] = 0;
     __syncthreads();
     const int ox = s_org[0], oy = s_org[1];
 
@@ -252,18 +253,26 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     }
     __syncthreads();
     MSTAMP(1);
-    // 3x3 dilation and 4x4 max-pool of the dilated field
-    for (int q = tid; q < N * W; q += MBLOCK) {
-        const int u = q / W, wv = q % W;
-        uint32_t acc = 0;
-        for (int du = -1; du <= 1; ++du) {
-            int uu = u + du;
-            if (uu < 0 || uu >= N) continue;
-            uint32_t c = s.occ[uu * W + wv];
-            uint32_t l = wv > 0 ? s.occ[uu * W + wv - 1] : 0, r = wv + 1 < W ? s.occ[uu * W + wv + 1] : 0;
-            acc |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+    // 3x3 dilation and 4x4 max-pool of the dilated field.  A thread takes one column word and a run of rows and slides
+    // a three-row window of horizontally dilated words down it: three LDS reads per row instead of nine.
+    {
+        const int nchunk = max(1, MBLOCK / W), rows_per = (N + nchunk - 1) / nchunk;
+        const int wv = tid % W, chunk = tid / W;
+        auto hdil = [&](int u) -> uint32_t {
+            if (u < 0 || u >= N) return 0u;
+            const uint32_t c = s.occ[u * W + wv];
+            const uint32_t l = wv > 0 ? s.occ[u * W + wv - 1] : 0u, r = wv + 1 < W ? s.occ[u * W + wv + 1] : 0u;
+            return c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+        };
+        if (chunk < nchunk) {
+            const int u0 = chunk * rows_per, u1 = min(N, u0 + rows_per);
+            uint32_t up = hdil(u0 - 1), mid = hdil(u0);
+            for (int u = u0; u < u1; ++u) {
+                const uint32_t dn = hdil(u + 1);
+                s.dil[u * W + wv] = up | mid | dn;
+                up = mid; mid = dn;
+            }
         }
-        s.dil[q] = acc;
     }
     __syncthreads();
     // one coarse word (32 coarse columns = 128 field columns) per thread: OR of its four field rows, then every
