@@ -435,8 +435,8 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t bo = ((ol[k] >> sh[k]) | (sh[k] ? oh[k] << (32 - sh[k]) : 0u)) & 0x1FFu;
-                        const uint32_t bd = ((dl[k] >> sh[k]) | (sh[k] ? dh[k] << (32 - sh[k]) : 0u)) & 0x1FFu;
+                        const uint32_t bo = __builtin_amdgcn_alignbit(oh[k], ol[k], (uint32_t)sh[k]) & 0x1FFu;   // funnel shift of hi:lo
+                        const uint32_t bd = __builtin_amdgcn_alignbit(dh[k], dl[k], (uint32_t)sh[k]) & 0x1FFu;
                         accA += (((bo & 0xFu) * 0x00204081u) & 0x01010101u) + (((bd & 0xFu) * 0x00204081u) & 0x01010101u);
                         accB += ((((bo >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) + ((((bd >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
                         accC += (int)(bo >> 8) + (int)(bd >> 8);
