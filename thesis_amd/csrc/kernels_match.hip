@@ -66,7 +66,9 @@ struct MatchLds {
     int* sc;            // [n coarse candidates] then reused for fine
 };
 
-__host__ __device__ inline int match_crs_words(int N) { return ((N / M_COARSE) + 31) / 32; }
+// the coarse map is stored with overlapping words: word h of a row holds coarse columns [16h, 16h + 32), so that any
+// 8 neighbouring columns lie inside ONE word
+__host__ __device__ inline int match_crs_words(int N) { return ((N / M_COARSE) + 15) / 16; }
 
 size_t match_lds_bytes(int N, int B, int n_coarse) {
     size_t words = (size_t)N * (N / 32);
@@ -85,7 +87,7 @@ __device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w)
 __device__ __forceinline__ int coarse_hit(const MatchLds& s, int N, int u, int w) {
     if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0;
     int cu = u / M_COARSE, cw = w / M_COARSE;
-    return (s.crs[cu * match_crs_words(N) + (cw >> 5)] >> (cw & 31)) & 1u;
+    return (s.crs[cu * match_crs_words(N) + (cw >> 4)] >> (cw & 15)) & 1u;
 }
 
 __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
@@ -275,14 +277,14 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         }
     }
     __syncthreads();
-    // one coarse word (32 coarse columns = 128 field columns) per thread: OR of its four field rows, then every
-    // 4-bit group of the four words collapses into one bit
+    // one coarse word per thread: two 16-column halves, each the OR of four field rows of two field words whose 4-bit
+    // groups collapse into one bit
     for (int q = tid; q < (N / M_COARSE) * match_crs_words(N); q += MBLOCK) {
-        const int cu = q / match_crs_words(N), cwv = q % match_crs_words(N);
+        const int cu = q / match_crs_words(N), h = q % match_crs_words(N);
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int wv = 4 * cwv + k;
+            const int wv = 2 * h + k;                                   // field words 2h .. 2h + 3 = coarse columns 16h .. 16h + 31
             uint32_t d = 0;
             if (wv < W) {
 #pragma unroll
@@ -343,15 +345,13 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                         const int u0 = (int)floorf(cs * bxs - sn * bys + fx) + (t0 - max(ktx, 0)) * M_COARSE;
                         const int cw0 = (int)floorf(sn * bxs + cs * bys + ty0) >> 2;         // candidate j looks at coarse column cw0 + j
                         const bool col_ok = cw0 >= 0 && cw0 + 7 < NC4;
-                        const int sh = cw0 & 31, wi = cw0 >> 5;
-                        const bool two = sh > 24 && wi + 1 < CW;
+                        const int sh = cw0 & 15, wi = cw0 >> 4;                              // one overlapping word holds all 8
 #pragma unroll
                         for (int t = 0; t < MAXTX; ++t) {
                             const int u = u0 + t * M_COARSE;
                             const bool in = col_ok && t0 + t < ntx && (unsigned)u < (unsigned)N;
                             const int i0 = in ? (u >> 2) * CW + wi : 0;
-                            const uint32_t lo = in ? s.crs[i0] : 0u, hi = (in && two) ? s.crs[i0 + 1] : 0u;
-                            const uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh) & 0xFFu;   // funnel shift of hi:lo
+                            const uint32_t bits = in ? (s.crs[i0] >> sh) & 0xFFu : 0u;
                             accA[t] += ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
                             accB[t] += ((bits >> 4) * 0x00204081u) & 0x01010101u;
                         }
