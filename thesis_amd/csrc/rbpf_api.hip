@@ -175,7 +175,9 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         for (int k = 0; k < rbpf_handle::N_KERN; ++k)
             for (int e = 0; e < 2; ++e) {
                 h->ring[k][e].resize(rbpf_handle::RING);
-                for (auto& ev : h->ring[k][e]) HIP_TRY(h, hipEventCreate(&ev));
+                // timing only: no system-scope fence when the event completes (it would flush the caches between the
+                // kernels it brackets and slow the very thing it measures)
+                for (auto& ev : h->ring[k][e]) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
             }
         const size_t P = v.P, LL = (size_t)v.L * v.L, cells = (size_t)dim * dim;
         uint32_t* d_lut; ALLOC(h, d_lut, h->h_lut.size()); v.lut = d_lut;
@@ -220,7 +222,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
         ALLOC(h, h->d_did_early, 1);
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_early, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
         {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle (tests, comparisons)
