@@ -214,7 +214,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             for (int r = 0; r < 3; ++r) {
                 rings[r]->slot_bytes = (bytes[r] + 255) & ~(size_t)255;
                 HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&rings[r]->base), rings[r]->slot_bytes * rbpf_handle::PinnedRing::N, hipHostMallocDefault));
-                for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) HIP_TRY(h, hipEventCreateWithFlags(&rings[r]->ev[i], hipEventDisableTiming));
+                for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) HIP_TRY(h, hipEventCreateWithFlags(&rings[r]->ev[i], hipEventDisableTiming | hipEventDisableSystemFence));   // guards host memory the copy only reads
             }
         }
         ALLOC(h, v.upd_pose, 3 * P);
@@ -224,7 +224,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_early, hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming | hipEventDisableSystemFence));
         {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle (tests, comparisons)
             const char* mk = getenv("RBPF_MAP_KERNEL");
             v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
