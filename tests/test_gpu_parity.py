@@ -450,3 +450,28 @@ def test_full_size_step_properties_c3(eng_mod):
         (centre, cells), = e.tiles(p)
         assert centre == (0.0, 0.0) and cells.min() >= -30 and cells.max() <= 30 and np.count_nonzero(cells) > 40000
     e.close()
+
+
+@pytest.mark.parametrize("B", [1, 2, 4095])
+def test_map_update_extreme_beam_counts(eng_mod, B):
+    """The smallest scans and the largest the ABI admits (max_beams <= 4095; more rays than either map kernel has
+    threads, the whole-fan kernel's tables do not hold them and the window kernel takes over), cell-exact.
+    The poses sit off the lattice lines on purpose: with the sensor exactly on a cell boundary and a beam that exactly
+    cancels the heading, the end point lands on the boundary up to the last ulp of sin/cos, where the device's and
+    numpy's libm may round to different cells (parity notes)."""
+    rng = np.random.Generator(np.random.PCG64(B))
+    ang = np.linspace(-2.3, 2.3, B) if B > 1 else np.array([0.4])
+    r = rng.uniform(0.5, 9.0, B)
+    poses = np.array([[0.313, -0.227, 0.5], [-4.011, 2.519, -1.0]])
+    e = eng_mod.ParticleEngine(2, max_beams=4095, pool_tiles=16)
+    maps = [orc.OracleHybridMap(0.05) for _ in range(2)]
+    for k in range(2):
+        e.set_scan(r * (1.0 + 0.1 * k), ang)
+        e.map_update(poses)
+        sx, sy = orc.scan_xy(r * (1.0 + 0.1 * k), ang)
+        for p in range(2):
+            maps[p].update(tuple(float(v) for v in poses[p]), sx, sy)
+    for p in range(2):
+        assert_tiles_equal(e, p, oracle_dump(maps[p]), e.dim)
+    assert e.counters()["ray_cells_visited"] == sum(m.cells_visited for m in maps)
+    e.close()
