@@ -32,6 +32,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 PERIOD_S = 0.7                 # one accepted scan every 0.35 m of travel (main.py:42 DIST_THRESHOLD = 0.33)
 
 
+NDT_DEFAULT = 1
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,6 +43,8 @@ def parse():
     ap.add_argument("--particles", type=int, default=1024, help="particles per GPU")
     ap.add_argument("--beams", type=int, default=1081)
     ap.add_argument("--cell-size", type=float, default=0.05)
+    ap.add_argument("--ndt", type=int, default=NDT_DEFAULT, choices=(0, 1),
+                    help="second matcher stage (matchScanCustom.m:32-50, NDT refinement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-run", action="store_true", help="skip the extra 10 240-particle measurement")
     return ap.parse_args()
@@ -48,12 +53,13 @@ def parse():
 class Runner:
     """The reference's event loop body for accepted scans, on one rank."""
 
-    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None, device=0):
+    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None, device=0, ndt=0):
         from thesis_amd.engine import ParticleEngine
         self.P, self.B, self.rank, self.world = P, B, rank, world
         self.angles, self.ranges, self.odo, self.true_poses = log
         # the seed is global: proposal streams are keyed by (seed, step, global particle id)
-        self.e = ParticleEngine(P, max_beams=B, cell_size=cell_size, pool_tiles=2 * P + 64, seed=42, device=device)
+        self.e = ParticleEngine(P, max_beams=B, cell_size=cell_size, pool_tiles=2 * P + 64, seed=42, device=device,
+                                ndt_refine=ndt)
         self.shard = shard
         if shard is not None:
             shard.attach(self.e)
@@ -123,6 +129,21 @@ def pmc_traffic(kernel, particles):
     return None if d is None else 2.0 * d["fetch_raw_bytes"] + d["write_bytes"]
 
 
+def copy_peak_gbs(torch, nbytes=1 << 30, reps=10):
+    """Measured HBM peak of a plain device-to-device copy (read + write bytes / time), SURVEY section 8(d)."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(log, B, cell_size, seconds=12.0):
     """Reference-equivalent CPU path (oracle/rbpf_oracle.c, pinned bit-exact to the reference's outputs):
     Robot.map_update without the MATLAB scan matcher (as BASELINE.md section 2), all host cores."""
@@ -184,7 +205,7 @@ def main():
     if dist is not None:
         from thesis_amd.sharding import ShardedResampler
         shard = ShardedResampler(rank, world, args.particles, device=local_rank, dist=dist)
-    run = Runner(args.particles, args.beams, args.cell_size, log, rank, world, shard, device=local_rank)
+    run = Runner(args.particles, args.beams, args.cell_size, log, rank, world, shard, device=local_rank, ndt=args.ndt)
 
     def barrier():
         if dist is not None:
@@ -240,6 +261,9 @@ def main():
                 "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,
                 "achieved_stored_bytes_GBs": ach / 4.0,
                 "kernel_ms_mean": mean_ms, "slow_cells_per_step": c["slow_cells"] / n_upd,
+                "ndt": {"enabled": bool(args.ndt), "runs_per_step": c["ndt_runs"] / n_upd,
+                        "evaluations_per_run": c["ndt_evaluations"] / max(1, c["ndt_runs"]),
+                        "accepted_fraction": c["ndt_accepted"] / max(1, c["ndt_runs"])},
                 "window_fallback_particles_per_step": c["window_fallbacks"] / n_upd,
                 "unique_cells_written_per_particle": W_per_particle,
                 "ray_cells_per_particle": cells_per_particle}
@@ -257,9 +281,12 @@ def main():
                              "migrated_particles_per_step": float(moved[0].item()) / (2 * max(1, args.steps + args.warmup)),
                              "migrated_bytes_per_step": float(moved[1].item()) / max(1, args.steps + args.warmup)}
     run.e.close()
+    if world == 1:
+        roofline["peak_measured_copy"] = copy_peak_gbs(torch)        # after the timed region, on an idle device
+        roofline["frac_of_measured_copy"] = ach / roofline["peak_measured_copy"]
     if not args.no_target_run and world == 1:
         # north-star target size: >= 10k particles x 1081 beams on one GPU (not `value`)
-        big = Runner(10240, args.beams, args.cell_size, log)
+        big = Runner(10240, args.beams, args.cell_size, log, ndt=args.ndt)
         for _ in range(3):
             big.step()
         big.e.set_profiling(True)

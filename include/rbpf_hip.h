@@ -73,7 +73,11 @@ typedef struct rbpf_config {
     double  vel_noise[4];     /* RBPF_IMU_VELOCITY Q: (a0 + a1|v|dt)^2, (b0 deg + b1|w|dt)^2;
                                  Freid101IMUData.py:51-55 => {0.02, 0.01, 0.2, 0.02}             */
     int32_t device;           /* HIP device ordinal                                               */
-    int32_t reserved0;
+    int32_t ndt_refine;       /* second matcher stage, matchScanCustom.m:32-50 (NDT, CellSize 0.1 m, 500 iterations):
+                                 0 off; 1 (default) on, accepted by the reference's rule (valid pose and
+                                 2*ndtScore > gridScore);
+                                 2 on, every valid NDT pose is taken (diagnostic).  Inactive when the matcher cell
+                                 is 0.1 m or coarser (no NDT cell can hold the 3 points a Gaussian needs).          */
     uint64_t seed;            /* Philox seed for on-device proposal sampling                      */
 } rbpf_config;
 
@@ -94,6 +98,9 @@ typedef struct rbpf_counters {
     uint64_t slow_cells;          /* flagged cells replayed by the exact membership scan          */
     uint64_t reserved[7];         /* phase cycle sums of a -DRBPF_STAMPS diagnostic build, else 0 */
     uint64_t window_fallbacks;    /* particles the whole-fan map update handed to the 128x128-window kernel */
+    uint64_t ndt_runs;            /* matches that entered the NDT stage                           */
+    uint64_t ndt_evaluations;     /* NDT score/gradient/Hessian evaluations, summed over runs     */
+    uint64_t ndt_accepted;        /* runs whose pose replaced the grid pose (matchScanCustom.m:39-41) */
 } rbpf_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

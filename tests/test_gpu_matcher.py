@@ -15,7 +15,7 @@ def rot(th):
 @pytest.fixture(scope="module")
 def eng():
     from thesis_amd.engine import ParticleEngine
-    e = ParticleEngine(4, max_beams=1081)
+    e = ParticleEngine(4, max_beams=1081, ndt_refine=0)      # the grid stage on its own
     yield e
     e.close()
 
@@ -156,3 +156,128 @@ def test_field_staging_fast_path_equals_bit_by_bit(monkeypatch):
         e.close()
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+# ---- NDT refinement stage (matchScanCustom.m:32-50; rbpf_config.ndt_refine) -----------------------------------------
+def wall_points(half=5.0, thick=2, cs=0.05):
+    """Reference points of a square room whose walls are `thick` cells thick, on the cell-corner lattice the
+    reference's point lists live on (gridmap.py:333-334)."""
+    k = int(round(half / cs))
+    line = np.arange(-k, k + 1)
+    pts = []
+    for t in range(thick):
+        for sgn in (-1, 1):
+            pts += [np.stack([np.full_like(line, sgn * (k + t)), line], 1), np.stack([line, np.full_like(line, sgn * (k + t))], 1)]
+    return np.unique(np.concatenate(pts), axis=0).astype(np.float64) * cs
+
+
+@pytest.fixture(scope="module")
+def eng_ndt():
+    from thesis_amd.engine import ParticleEngine
+    e = ParticleEngine(4, max_beams=1081, ndt_refine=2)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_grid():
+    from thesis_amd.engine import ParticleEngine
+    e = ParticleEngine(4, max_beams=1081, ndt_refine=0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("off", [(0.013, -0.021, 0.0007), (0.31, 0.18, -0.11), (-0.44, 0.27, 0.2)])
+def test_ndt_stage_equals_oracle(eng_grid, eng_ndt, off):
+    """The HIP NDT stage against oracle/matcher_oracle.py, both started from the correlative optimum: same pose, same
+    score, same number of evaluations.  (Against MATLAB's matchScans: parity unpinned.)"""
+    from thesis_amd.engine import match_scan
+    from oracle import matcher_oracle as mo
+    ref = wall_points()
+    inner = ref[(np.abs(ref[:, 0]) <= 5.0) & (np.abs(ref[:, 1]) <= 5.0)][::3]     # the scan sees the inner face
+    dx, dy, dth = off
+    curr = (inner - [dx, dy]) @ rot(dth)
+    rng3 = [0.7, 0.7, np.pi / 6]
+    p0, cov0, s0 = match_scan(eng_grid, curr, ref, [0, 0, 0], 20, rng3)
+    before = eng_ndt.counters()
+    p1, cov1, s1 = match_scan(eng_ndt, curr, ref, [0, 0, 0], 20, rng3)
+    after = eng_ndt.counters()
+    assert np.all(np.isfinite(cov0)) and np.array_equal(cov0, cov1)               # the covariance stays the grid one
+    mcs, N = 0.05, 672                                                            # stateless twin: MaxRange 15 => 672 cells
+    occ, ox, oy = mo.rasterise(ref, [0, 0, 0], mcs, N, 0.5, 15.0)
+    pts = mo.beams_in_cells(curr, mcs)
+    X0, Y0 = 0.0 / mcs - ox + 0.5, 0.0 / mcs - oy + 0.5
+    start = (X0 + p0[0] / mcs, Y0 + p0[1] / mcs, p0[2])
+    pw, score, evals = mo.ndt_refine(occ, pts, start, 2, ox, oy)
+    want = np.array([(pw[0] - X0) * mcs, (pw[1] - Y0) * mcs, pw[2]])
+    assert after["ndt_runs"] - before["ndt_runs"] == 1 and after["ndt_accepted"] - before["ndt_accepted"] == 1
+    assert after["ndt_evaluations"] - before["ndt_evaluations"] == evals
+    assert np.allclose(p1, want, rtol=0, atol=1e-6)                 # metres / radians; float terms, expf vs numpy's exp
+    assert abs(s1 - score) <= 1e-6 * score
+    # the ascent is monotone and stays within a cell of the constructed offset (the Gaussians sit on the middle of the
+    # two-cell walls while the points lie on their inner face: a bias below one cell, not an error of the stage)
+    assert score >= -mo.ndt_eval(occ, pts, start, 2, ox, oy, True)[0] - 1e-6 * score
+    assert abs(p1[0] - dx) < 0.05 and abs(p1[1] - dy) < 0.05 and abs(p1[2] - dth) < 8e-3
+
+
+def test_ndt_acceptance_rule(eng_grid, eng_ndt):
+    """matchScanCustom.m:38-44: the NDT pose is taken iff it is valid and 2 * ndtScore > gridScore."""
+    from thesis_amd.engine import ParticleEngine, match_scan
+    ref = wall_points()
+    inner = ref[(np.abs(ref[:, 0]) <= 5.0) & (np.abs(ref[:, 1]) <= 5.0)][::3]
+    curr = (inner - [0.12, -0.07]) @ rot(0.01)
+    e1 = ParticleEngine(1, max_beams=1081, ndt_refine=1)
+    try:
+        for r in (ref, ref[::7]):            # dense walls: NDT cells hold >= 3 points; thinned: almost none do
+            pg, _, sg = match_scan(eng_grid, curr, r, [0, 0, 0], 20, [0.7, 0.7, np.pi / 6])
+            pa, _, sa = match_scan(eng_ndt, curr, r, [0, 0, 0], 20, [0.7, 0.7, np.pi / 6])   # always-take mode: the NDT score
+            p1, _, s1 = match_scan(e1, curr, r, [0, 0, 0], 20, [0.7, 0.7, np.pi / 6])
+            if 2 * sa > sg:
+                assert np.array_equal(p1, pa) and s1 == sa
+            else:
+                assert np.array_equal(p1, pg) and s1 == sg
+        assert e1.counters()["ndt_runs"] == 2 and e1.counters()["ndt_accepted"] == 1
+    finally:
+        e1.close()
+
+
+def test_ndt_inactive_when_cells_cannot_hold_three_points():
+    """0.1 m matcher cells (config C1): an NDT cell of 0.1 m is one matcher cell, no Gaussian can be formed."""
+    from thesis_amd.engine import ParticleEngine, match_scan
+    ref = wall_points(cs=0.1)
+    e = ParticleEngine(1, max_beams=1081, cell_size=0.1, ndt_refine=1)
+    try:
+        pose, cov, score = match_scan(e, ref[::2], ref, [0, 0, 0], 10, [0.7, 0.7, np.pi / 6])
+        assert np.all(np.isfinite(cov)) and e.counters()["ndt_runs"] == 0
+    finally:
+        e.close()
+
+
+def test_scan_update_with_ndt_stage_runs_per_particle():
+    """The engine path: every particle's match enters the NDT stage, and the posterior is at least as close to the
+    truth as the grid stage alone leaves it."""
+    from thesis_amd.engine import ParticleEngine
+    from thesis_amd.datasets import synthetic
+    P = 16
+    true0, true1 = np.array([0.5, -0.3, 0.2]), np.array([0.8, -0.1, 0.3])
+    ang = synthetic.beam_angles(1081)
+    errs = {}
+    for mode in (0, 1):
+        rng = np.random.Generator(np.random.PCG64(11))
+        e = ParticleEngine(P, max_beams=1081, ndt_refine=mode)
+        for _ in range(8):
+            e.set_scan(synthetic.cast_scan(true0, ang, rng), ang)
+            e.map_update(np.broadcast_to(true0, (P, 3)))
+        r1 = synthetic.cast_scan(true1, ang, rng)
+        err = np.stack([rng.uniform(-0.3, 0.3, P), rng.uniform(-0.3, 0.3, P), rng.uniform(-0.15, 0.15, P)], axis=1)
+        e.set_state(poses=true1 + err, covs=np.diag([0.02 ** 2, 0.02 ** 2, 0.01 ** 2]), weights=1.0)
+        e.set_scan(r1, ang)
+        e.scan_update()
+        c = e.counters()
+        assert c["ndt_runs"] == (P if mode else 0) and c["ndt_accepted"] <= c["ndt_runs"]
+        assert c["ndt_evaluations"] >= c["ndt_runs"]
+        errs[mode] = np.abs(e.poses() - true1)
+        assert np.all(np.isfinite(e.weights())) and np.all(np.isfinite(e.covs()))
+        e.close()
+    assert np.all(errs[1][:, :2] < 0.08) and np.all(errs[1][:, 2] < 0.01)
+    print("mean |error| grid only", errs[0].mean(axis=0), "with NDT", errs[1].mean(axis=0))

@@ -25,7 +25,7 @@ class RbpfConfig(C.Structure):
         ("weight_min_range", C.c_double), ("weight_max_range", C.c_double),
         ("match_min_range", C.c_double), ("match_max_range", C.c_double),
         ("resample_spread", C.c_double), ("vel_noise", C.c_double * 4), ("device", C.c_int32),
-        ("reserved0", C.c_int32), ("seed", C.c_uint64),
+        ("ndt_refine", C.c_int32), ("seed", C.c_uint64),
     ]
 
 
@@ -35,7 +35,8 @@ class RbpfCounters(C.Structure):
         ("cells_gathered", C.c_uint64), ("tiles_in_use", C.c_uint64), ("resample_copies", C.c_uint64),
         ("bytes_copied", C.c_uint64), ("ms_raycast", C.c_double), ("ms_weight", C.c_double),
         ("ms_match", C.c_double), ("ms_resample", C.c_double), ("slow_cells", C.c_uint64),
-        ("reserved", C.c_uint64 * 7), ("window_fallbacks", C.c_uint64),
+        ("reserved", C.c_uint64 * 7), ("window_fallbacks", C.c_uint64), ("ndt_runs", C.c_uint64), ("ndt_evaluations", C.c_uint64),
+        ("ndt_accepted", C.c_uint64),
     ]
 
 

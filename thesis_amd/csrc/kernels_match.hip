@@ -18,7 +18,11 @@
 //   fine     around the coarse optimum: rotation step d0 = cell/max_range, translation step 1 cell,
 //            every 4th beam;
 //   cov      second moments of exp((s - s_best)/tau) over the fine candidates + a floor.
-// The NDT refinement (matchScanCustom.m:32-50) is not reproduced.
+//   ndt      (rbpf_config.ndt_refine) the second stage of matchScanCustom.m:32-50: Normal Distributions Transform
+//            (Biber & Strasser 2003, the algorithm MATLAB's matchScans documents) with the call site's CellSize 0.1 m
+//            and MaxIterations 500, started from the correlative optimum and accepted by the reference's rule
+//            (valid pose and 2 * ndtScore > gridScore; the covariance stays the grid one).  Restated on the CPU in
+//            oracle/matcher_oracle.py; MATLAB's own numerics stay unpinned.
 #include <limits.h>
 #include <string.h>
 
@@ -54,6 +58,11 @@ struct MatchArgs {
     int n_coarse_rot;           // rotations on each side at the coarse level
     int cap_sel;                // LDS capacity for selected beams
     double cell_off;            // 0.5 in the stateless twin: its points are snapped to cell corners (hybridmap.py:226-227)
+    int ndt;                    // 0 off; 1 matchScanCustom.m:38-44 acceptance; 2 take every valid NDT pose (diagnostic)
+    int ndt_nc;                 // NDT cell edge in matcher cells (0.1 m, matchScanCustom.m:37); < 2: no cell can hold 3 points
+    int ndt_max_iter;           // matchScanCustom.m:36
+    uint32_t* ndt_occ;          // [particles][N][N/32] the staged occupancy field, handed to the NDT kernel
+    double* ndt_aux;            // [particles][5] grid optimum (cells, cells, rad), its full score, ok flag
 };
 
 struct MatchLds {
@@ -90,6 +99,23 @@ __device__ __forceinline__ int coarse_hit(const MatchLds& s, int N, int u, int w
     return (s.crs[cu * match_crs_words(N) + (cw >> 4)] >> (cw & 15)) & 1u;
 }
 
+// guess, search window (robot.py:62-65) and region origin of one match problem
+__device__ inline void match_frame(const DevView& v, const MatchArgs& a, int p, double* g, double* rng, int* org) {
+    double gx, gy, gth, rx, ry;
+    if (a.single) {
+        gx = a.guess[0]; gy = a.guess[1]; gth = a.guess[2]; rx = a.range[0]; ry = a.range[1];
+    } else {
+        gx = v.px[p]; gy = v.py[p]; gth = v.pth[p];
+        double c00 = v.cov[(size_t)0 * v.P + p], c11 = v.cov[(size_t)4 * v.P + p];
+        double p0 = sqrt(c00) * 30.0, p1 = sqrt(c11) * 30.0;                 // robot.py:62
+        ry = fmax(fmin(4 * p1, 0.7), 0.1);                                   // robot.py:64
+        rx = fmax(fmin(4 * p0, 0.7), 0.1);                                   // robot.py:65
+    }
+    g[0] = gx; g[1] = gy; g[2] = gth; rng[0] = rx; rng[1] = ry;
+    org[0] = (int)floor(gx / a.mcs) - a.N / 2;
+    org[1] = (int)floor(gy / a.mcs) - a.N / 2;
+}
+
 __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, W = N >> 5, tid = threadIdx.x, p = blockIdx.x;
@@ -114,19 +140,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
 #endif
     // ---- guess, search window (robot.py:62-65), region origin ----------------------------------------------
     if (tid == 0) {
-        double gx, gy, gth, rx, ry;
-        if (a.single) {
-            gx = a.guess[0]; gy = a.guess[1]; gth = a.guess[2]; rx = a.range[0]; ry = a.range[1];
-        } else {
-            gx = v.px[p]; gy = v.py[p]; gth = v.pth[p];
-            double c00 = v.cov[(size_t)0 * v.P + p], c11 = v.cov[(size_t)4 * v.P + p];
-            double p0 = sqrt(c00) * 30.0, p1 = sqrt(c11) * 30.0;                 // robot.py:62
-            ry = fmax(fmin(4 * p1, 0.7), 0.1);                                   // robot.py:64
-            rx = fmax(fmin(4 * p0, 0.7), 0.1);                                   // robot.py:65
-        }
-        s_g[0] = gx; s_g[1] = gy; s_g[2] = gth; s_rng[0] = rx; s_rng[1] = ry;
-        s_org[0] = (int)floor(gx / a.mcs) - N / 2;
-        s_org[1] = (int)floor(gy / a.mcs) - N / 2;
+        match_frame(v, a, p, s_g, s_rng, s_org);
         s_nb = 0; s_best = INT_MIN; s_bestc = 0; s_slowg = 0;
         for (int i = 0; i < 10; ++i) s_mom[i] = 0.0;
     }
@@ -254,6 +268,10 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         if (tid == 0) s_nb = a.n_sel;
     }
     __syncthreads();
+    if (a.ndt_occ) {                                          // the NDT kernel reads the same field (32 KB per particle)
+        uint32_t* dst = a.ndt_occ + (size_t)p * N * W;
+        for (int i = tid; i < N * W; i += MBLOCK) dst[i] = s.occ[i];
+    }
     MSTAMP(1);
     // 3x3 dilation and 4x4 max-pool of the dilated field.  A thread takes one column word and a run of rows and slides
     // a three-row window of horizontally dilated words down it: three LDS reads per row instead of nine.
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     __syncthreads();
     MSTAMP(5);
 #ifdef RBPF_STAMPS
-    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+    if (tid == 0 && !a.ndt_occ) for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);   // with the NDT stage on, its kernel reports
 #endif
     if (tid == 0) {
         double* o = a.out + (size_t)p * 13;
@@ -545,8 +563,284 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 + 3 * i + j] = c[i][j];
             o[12] = 0.5 * (double)full_score;
         }
+        if (a.ndt_aux) {
+            double* x = a.ndt_aux + (size_t)p * 5;
+            x[0] = bdx / a.mcs; x[1] = bdy / a.mcs; x[2] = bth; x[3] = (double)full_score; x[4] = ok ? 1.0 : 0.0;
+        }
     }
 }
+
+// ---- NDT refinement (oracle/matcher_oracle.py states the algorithm) ---------------------------------------------
+// The reference cloud is the occupancy bitmask itself: the points of an NDT cell are the centres of its occupied
+// matcher cells, so a cell's mean and covariance follow from integer sums over its nc x nc bits.
+struct NdtCell { double mx, my, b00, b01, b11; };          // mean (offset from the cell's first matcher cell), inverse covariance
+struct NdtCellF { double mx, my; float b00, b01, b11, pad; };   // the table entry of the single-precision path (32 bytes)
+__device__ inline bool ndt_cell_stats(int n, int sx, int sy, int sxx, int sxy, int syy, NdtCell& c) {
+    if (n < 3) return false;
+    const double nn = (double)n, mx = (double)sx / nn, my = (double)sy / nn;
+    const double ca = ((double)sxx - (double)sx * mx) / (nn - 1.0);
+    const double cb = ((double)sxy - (double)sx * my) / (nn - 1.0);
+    const double cc = ((double)syy - (double)sy * my) / (nn - 1.0);
+    const double half_tr = 0.5 * (ca + cc), disc = sqrt(0.25 * (ca - cc) * (ca - cc) + cb * cb);
+    const double l1 = half_tr + disc, l2 = half_tr - disc;
+    double k = 0.0;
+    if (l2 < 1e-3 * l1) { k = (1e-3 * l1 - l2) / (l1 - l2); if (!(fabs(k) <= 1.79e308)) k = 0.0; }   // smaller eigenvalue >= 0.001 * larger
+    const double a2 = ca + k * (l1 - ca), b2 = cb + k * (-cb), c2 = cc + k * (l1 - cc);
+    const double det = a2 * c2 - b2 * b2;
+    c.mx = mx; c.my = my; c.b00 = c2 / det; c.b01 = -b2 / det; c.b11 = a2 / det;
+    return true;
+}
+// one (beam, NDT cell) term of f = -score, its gradient and Hessian: m[0..9] = f, g x y t, H xx xy xt yy yt tt
+__device__ __forceinline__ void ndt_term(const NdtCell& c, double qx0, double qy0, double ex, double ey, double rx, double ry, double* m) {
+    const double dx = ex - (qx0 + 0.5 + c.mx), dy = ey - (qy0 + 0.5 + c.my);
+    const double e0 = c.b00 * dx + c.b01 * dy, e1 = c.b01 * dx + c.b11 * dy;
+    const double sg = exp(-0.5 * (dx * e0 + dy * e1));
+    const double c0 = e0, c1 = e1, c2 = e0 * (-ry) + e1 * rx;
+    const double bj0 = c.b00 * (-ry) + c.b01 * rx, bj1 = c.b01 * (-ry) + c.b11 * rx;
+    m[0] -= sg;
+    m[1] += sg * c0; m[2] += sg * c1; m[3] += sg * c2;
+    m[4] += sg * (-c0 * c0 + c.b00);
+    m[5] += sg * (-c0 * c1 + c.b01);
+    m[6] += sg * (-c0 * c2 + bj0);
+    m[7] += sg * (-c1 * c1 + c.b11);
+    m[8] += sg * (-c1 * c2 + bj1);
+    m[9] += sg * (-c2 * c2 + (-ry) * bj0 + rx * bj1 + e0 * (-rx) + e1 * (-ry));
+}
+// The same term in single precision (the hot form): the offset from the cell mean is formed in double (coordinates
+// run to hundreds of cells) and is small; everything after it is float, summed per thread in float and across threads in
+// double.  oracle/matcher_oracle.py follows the same split.
+__device__ __forceinline__ void ndt_term32(float b00, float b01, float b11, float dx, float dy, float rx, float ry, float live, float* m) {
+    const float e0 = b00 * dx + b01 * dy, e1 = b01 * dx + b11 * dy;
+    const float sg = live * expf(-0.5f * (dx * e0 + dy * e1));
+    const float c0 = e0, c1 = e1, c2 = e0 * (-ry) + e1 * rx;
+    const float bj0 = b00 * (-ry) + b01 * rx, bj1 = b01 * (-ry) + b11 * rx;
+    m[0] -= sg;
+    m[1] += sg * c0; m[2] += sg * c1; m[3] += sg * c2;
+    m[4] += sg * (-c0 * c0 + b00);
+    m[5] += sg * (-c0 * c1 + b01);
+    m[6] += sg * (-c0 * c2 + bj0);
+    m[7] += sg * (-c1 * c1 + b11);
+    m[8] += sg * (-c1 * c2 + bj1);
+    m[9] += sg * (-c2 * c2 + (-ry) * bj0 + rx * bj1 + e0 * (-rx) + e1 * (-ry));
+}
+__device__ __forceinline__ uint32_t ndt_bit(const uint32_t* occ, int N, int u, int w) {
+    if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0u;
+    return (occ[u * (N >> 5) + (w >> 5)] >> (w & 31)) & 1u;
+}
+// One beam at the pose (tx, ty, theta), region cell units; four overlapping grids shifted by half an NDT cell and
+// anchored to the global cell index: the general form.  (nc == 2, i.e. 0.05 m matcher cells -- every shipped
+// configuration -- goes through a 16-entry table by 2 x 2 occupancy pattern in the kernel instead.)
+__device__ __forceinline__ void ndt_point(const uint32_t* occ, int N, int nc, int ox, int oy,
+                                          double bx, double by, double tx, double ty, double sn, double cs, double* m) {
+    const double rx = cs * bx - sn * by, ry = sn * bx + cs * by;
+    const double ex = rx + tx, ey = ry + ty;
+    const int u = (int)floor(ex), w = (int)floor(ey);
+    if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return;
+    const int h = nc >> 1;
+    for (int g = 0; g < 4; ++g) {
+        const int gx = (g & 1) ? h : 0, gy = (g & 2) ? h : 0;
+        int mu = (u + ox - gx) % nc; if (mu < 0) mu += nc;
+        int mw = (w + oy - gy) % nc; if (mw < 0) mw += nc;
+        const int u0 = u - mu, w0 = w - mw;
+        int n = 0, sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;
+        for (int i = 0; i < nc; ++i)
+            for (int j = 0; j < nc; ++j)
+                if (ndt_bit(occ, N, u0 + i, w0 + j)) { ++n; sx += i; sy += j; sxx += i * i; sxy += i * j; syy += j * j; }
+        NdtCell c;
+        if (!ndt_cell_stats(n, sx, sy, sxx, sxy, syy, c)) continue;
+        ndt_term(c, (double)u0, (double)w0, ex, ey, rx, ry, m);
+    }
+}
+
+// (H + lam * diag(|H_ii| + 1e-12)) d = -g by Cholesky; false when the damped matrix is not positive definite
+__device__ inline bool ndt_lm_step(const double* m, double lam, double* d) {
+    const double A00 = m[4] + lam * (fabs(m[4]) + 1e-12), A11 = m[7] + lam * (fabs(m[7]) + 1e-12), A22 = m[9] + lam * (fabs(m[9]) + 1e-12);
+    const double A10 = m[5], A20 = m[6], A21 = m[8];
+    if (!(A00 > 0)) return false;
+    const double l00 = sqrt(A00), l10 = A10 / l00, l20 = A20 / l00;
+    const double d1 = A11 - l10 * l10;
+    if (!(d1 > 0)) return false;
+    const double l11 = sqrt(d1), l21 = (A21 - l20 * l10) / l11;
+    const double d2 = A22 - l20 * l20 - l21 * l21;
+    if (!(d2 > 0)) return false;
+    const double l22 = sqrt(d2);
+    const double y0 = -m[1] / l00, y1 = (-m[2] - l10 * y0) / l11, y2 = (-m[3] - l20 * y0 - l21 * y1) / l22;
+    d[2] = y2 / l22;
+    d[1] = (y1 - l21 * d[2]) / l11;
+    d[0] = (y0 - l10 * d[1] - l20 * d[2]) / l00;
+    return true;
+}
+
+static const int NBLOCK = 256;            // NDT kernel: threads per particle
+static const int NDT_STRIDE = 1;          // beams used by the ascent (1: all; the final score always uses all)
+
+size_t ndt_lds_bytes(int N, int B) { (void)B; return (size_t)N * (N / 32) * 4 + 64; }    // the field only: four workgroups per CU at N = 512
+
+// The second matcher stage (matchScanCustom.m:32-50) for the particles whose grid stage succeeded: damped Newton ascent
+// of the NDT score from the grid optimum.  Thread 0 holds the optimiser state; every evaluation is one pass over the
+// (beam, grid) pairs and a fixed-order reduction, so results do not depend on wave timing.
+__global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, W = N >> 5, tid = threadIdx.x, p = blockIdx.x;
+    uint32_t* occ = reinterpret_cast<uint32_t*>(smem);
+    const float* __restrict__ bx = a.sel_x;     // beams stay in global memory (the same 8.6 KB for every workgroup: L1/L2 hits)
+    const float* __restrict__ by = a.sel_y;
+    const float inv = (float)(1.0 / a.mcs);     // matcher cells per metre, float as the grid stage stages its beams
+    __shared__ double s_g[3], s_rng[2], s_trial[6], s_w[NBLOCK / 64][10];     // s_trial: pose, -, sin, cos
+    __shared__ int s_org[2], s_go;
+    __shared__ NdtCellF s_lut[16];              // statistics of a 2 x 2 NDT cell by occupancy pattern
+    __shared__ unsigned s_ok;
+#ifdef RBPF_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#endif
+    const double* aux = a.ndt_aux + (size_t)p * 5;
+    if (aux[4] == 0.0 || a.n_sel <= 0) return;                  // the grid stage failed: matchScanCustom.m:25-28, uniform
+    if (tid == 0) { match_frame(v, a, p, s_g, s_rng, s_org); s_ok = 0; }
+    {
+        const uint32_t* src = a.ndt_occ + (size_t)p * N * W;
+        for (int i = tid; i < N * W; i += NBLOCK) occ[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < 16) {             // pattern bit 0: cell (0,0), bit 1: (0,1), bit 2: (1,0), bit 3: (1,1)
+        const int b0 = tid & 1, b1 = (tid >> 1) & 1, b2 = (tid >> 2) & 1, b3 = (tid >> 3) & 1;
+        NdtCell c = {0, 0, 0, 0, 0};
+        if (ndt_cell_stats(b0 + b1 + b2 + b3, b2 + b3, b1 + b3, b2 + b3, b3, b1 + b3, c)) atomicOr(&s_ok, 1u << tid);
+        NdtCellF f = {c.mx, c.my, (float)c.b00, (float)c.b01, (float)c.b11, 0.0f};
+        s_lut[tid] = f;
+    }
+    const int ox = s_org[0], oy = s_org[1], nb = a.n_sel, nc = a.ndt_nc;
+    const double gth = s_g[2];
+    const double X0 = s_g[0] / a.mcs - (double)ox + a.cell_off, Y0 = s_g[1] / a.mcs - (double)oy + a.cell_off;
+    // the optimiser state lives in LDS: one thread uses it, and registers would be reserved for it in every lane
+    __shared__ double s_cur[10], s_pose[3], s_step[3], s_lam;
+    __shared__ int s_evals;
+    double* const cur = s_cur; double* const ndt_p = s_pose; double* const step = s_step;
+    double& lam = s_lam; int& evals = s_evals;
+    if (tid == 0) {
+        ndt_p[0] = X0 + aux[0]; ndt_p[1] = Y0 + aux[1]; ndt_p[2] = gth + aux[2];
+        lam = 1e-3; step[0] = step[1] = step[2] = 0.0; evals = 0;
+    }
+    if (tid == 0) { s_trial[0] = ndt_p[0]; s_trial[1] = ndt_p[1]; s_trial[2] = ndt_p[2]; sincos(ndt_p[2], &s_trial[4], &s_trial[5]); s_go = 1; }
+    __syncthreads();
+    MSTAMP(0);                                   // staging
+    const unsigned lut_ok = s_ok;
+    // one evaluation: every `stride`-th beam at the pose in s_trial; per-wave sums land in s_w (then a barrier)
+    auto evaluate = [&](int stride) {
+        const double tx = s_trial[0], ty = s_trial[1], snd = s_trial[4], csd = s_trial[5];
+        double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int nbs = (nb + stride - 1) / stride;
+        if (nc == 2) {
+            // one beam per lane and pass; its four grid terms are independent chains (branch-free: a term without a
+            // Gaussian is multiplied by zero), which is what hides the LDS and exp latencies
+            float mf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = tid; i < nbs; i += NBLOCK) {
+                const int b = i * stride;
+                const double bxd = (double)(bx[b] * inv), byd = (double)(by[b] * inv);
+                const double rx = csd * bxd - snd * byd, ry = snd * bxd + csd * byd;
+                const double ex = rx + tx, ey = ry + ty;
+                const int u = (int)floor(ex), w = (int)floor(ey);
+                const bool inside = (unsigned)u < (unsigned)N && (unsigned)w < (unsigned)N;
+                // the 3 x 3 occupancy bits around the beam's cell: bit 3 * r + c = cell (u - 1 + r, w - 1 + c)
+                uint32_t nb9 = 0;
+                {
+                    const int c0 = w - 1, wi = max(c0, 0) >> 5;
+                    uint32_t lo[3], hi[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int uu = u - 1 + r;
+                        const bool rok = inside && (unsigned)uu < (unsigned)N;
+                        const int base = (rok ? uu : 0) * W + (inside ? wi : 0);
+                        lo[r] = rok ? occ[base] : 0u;
+                        hi[r] = (rok && wi + 1 < W) ? occ[base + 1] : 0u;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const unsigned long long q = ((unsigned long long)hi[r] << 32) | lo[r];
+                        const uint32_t three = c0 < 0 ? ((uint32_t)q << 1) & 7u : (uint32_t)(q >> (c0 & 31)) & 7u;
+                        nb9 |= three << (3 * r);
+                    }
+                }
+                const float rxf = (float)rx, ryf = (float)ry;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int mu = (u + ox - (g & 1)) & 1, mw = (w + oy - ((g >> 1) & 1)) & 1;     // offset inside the NDT cell
+                    const int sh = 3 * (1 - mu) + (1 - mw);
+                    const uint32_t pat = ((nb9 >> sh) & 3u) | (((nb9 >> (sh + 3)) & 3u) << 2);
+                    const bool okg = inside && ((lut_ok >> pat) & 1u);
+                    const NdtCellF c = s_lut[pat];
+                    const float dx = (float)(ex - ((double)(u - mu) + 0.5 + c.mx)), dy = (float)(ey - ((double)(w - mw) + 0.5 + c.my));
+                    ndt_term32(c.b00, c.b01, c.b11, dx, dy, rxf, ryf, okg ? 1.0f : 0.0f, mf);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) m[k] = (double)mf[k];
+        } else {
+            for (int i = tid; i < nbs; i += NBLOCK) ndt_point(occ, N, nc, ox, oy, (double)(bx[i * stride] * inv), (double)(by[i * stride] * inv), tx, ty, snd, csd, m);
+        }
+        MSTAMP(1);                               // beams
+        for (int k = 0; k < 10; ++k) {
+            double x = m[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((tid & 63) == 0) s_w[tid >> 6][k] = x;
+        }
+        __syncthreads();
+        MSTAMP(2);                               // reduction + barrier
+    };
+    // (NDT_STRIDE > 1 would run the ascent on a subsample; the score that decides acceptance always covers all beams.)
+    for (;;) {
+        evaluate(NDT_STRIDE);
+        if (tid == 0) {
+            const double tx = s_trial[0], ty = s_trial[1], tt = s_trial[2];
+            double tr[10];
+            for (int k = 0; k < 10; ++k) { double x = 0.0; for (int w = 0; w < NBLOCK / 64; ++w) x += s_w[w][k]; tr[k] = x; }
+            bool go = true;
+            if (evals == 0) { for (int k = 0; k < 10; ++k) cur[k] = tr[k]; }
+            else if (tr[0] < cur[0]) {
+                for (int k = 0; k < 10; ++k) cur[k] = tr[k];
+                ndt_p[0] = tx; ndt_p[1] = ty; ndt_p[2] = tt;
+                lam = fmax(lam * 0.1, 1e-7);
+            } else {
+                lam *= 10.0;
+                if (lam > 1e7) go = false;
+            }
+            ++evals;
+            if (go && evals > a.ndt_max_iter) go = false;
+            if (go) {
+                bool have = false;
+                while (lam <= 1e7 && !(have = ndt_lm_step(cur, lam, step))) lam *= 10.0;
+                if (!have) go = false;
+                else if (fmax(fabs(step[0]), fabs(step[1])) < 5e-3 && fabs(step[2]) < 1e-4) go = false;   // converged: step below 0.005 cells, 1e-4 rad
+                else { s_trial[0] = ndt_p[0] + step[0]; s_trial[1] = ndt_p[1] + step[1]; s_trial[2] = ndt_p[2] + step[2]; }
+            }
+            if (!go) { s_trial[0] = ndt_p[0]; s_trial[1] = ndt_p[1]; s_trial[2] = ndt_p[2]; }
+            sincos(s_trial[2], &s_trial[4], &s_trial[5]);
+            s_go = go ? 1 : 0;
+        }
+        __syncthreads();
+        MSTAMP(3);                               // optimiser step (one thread) + barrier
+        if (!s_go) break;
+    }
+    if (NDT_STRIDE != 1) evaluate(1);
+    if (tid == 0) {
+        atomicAdd(&v.stats[ST_NDT_RUNS], 1ull); atomicAdd(&v.stats[ST_NDT_EVALS], (unsigned long long)evals);
+        // matchScanCustom.m:38-44: the NDT pose replaces the grid pose when it is inside the search window (:52-57)
+        // and twice its score exceeds the grid score; the covariance stays the grid one
+        double score = -cur[0];
+        if (NDT_STRIDE != 1) { score = 0.0; for (int w = 0; w < NBLOCK / 64; ++w) score -= s_w[w][0]; }
+        const double ddx = (ndt_p[0] - X0) * a.mcs, ddy = (ndt_p[1] - Y0) * a.mcs, ddt = ndt_p[2] - gth;
+        const bool valid = fabs(ddx) < s_rng[0] && fabs(ddy) < s_rng[1] && fabs(remainder(ddt, 6.283185307179586)) < a.rot_range &&
+                           (s_g[0] + ddx != 0.0 || s_g[1] + ddy != 0.0 || s_g[2] + ddt != 0.0);
+        if (valid && (a.ndt == 2 || 2.0 * score > 0.5 * aux[3])) {
+            double* o = a.out + (size_t)p * 13;
+            o[0] = s_g[0] + ddx; o[1] = s_g[1] + ddy; o[2] = s_g[2] + ddt; o[12] = score;
+            atomicAdd(&v.stats[ST_NDT_ACCEPTED], 1ull);
+        }
+#ifdef RBPF_STAMPS
+        for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+#endif
+    }
+}
+
 
 // region edge in matcher cells and the matcher-cell scale for a configuration
 void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot) {
@@ -580,6 +874,19 @@ static void launch_match(const DevView& v, const MatchArgs& a, int grid, size_t 
     hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, v, a);
 }
 
+// NDT cell edge in matcher cells for matchScanCustom.m:37 ('CellSize', 0.1)
+int ndt_cells(double mcs) { return (int)floor(0.1 / mcs + 0.5); }
+
+static void launch_ndt(const DevView& v, const MatchArgs& a, int grid, hipStream_t s) {
+    size_t lds = ndt_lds_bytes(a.N, a.cap_sel);
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ndt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL(ndt_kernel, dim3(grid), dim3(NBLOCK), lds, s, v, a);
+}
+
 void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
                             double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, hipStream_t s) {
     MatchArgs a;
@@ -588,12 +895,16 @@ void launch_match_particles(const DevView& v, int mode, const double* d_ref, int
     a.N = N; a.ds = ds; a.mcs = mcs; a.d0 = d0; a.rot_range = 3.141592653589793 / 6; a.max_range = max_range;
     a.sel_x = mode ? v.asel_x : v.msel_x; a.sel_y = mode ? v.asel_y : v.msel_y; a.n_sel = mode ? v.n_asel : v.n_msel;
     a.n_coarse_rot = ncr; a.cap_sel = cap_sel;
+    a.ndt = v.ndt_refine; a.ndt_nc = ndt_cells(mcs); a.ndt_max_iter = 500;
+    const bool ndt = a.ndt && a.ndt_nc >= 2 && v.ndt_occ;
+    if (ndt) { a.ndt_occ = v.ndt_occ; a.ndt_aux = v.ndt_aux; }
     launch_match(v, a, v.P, lds, s);
+    if (ndt) launch_ndt(v, a, v.P, s);
 }
 
 void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
                          const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
-                         double d0, int ncr, int cap_sel, size_t lds, hipStream_t s) {
+                         double d0, int ncr, int cap_sel, size_t lds, uint32_t* d_ndt_occ, double* d_ndt_aux, hipStream_t s) {
     MatchArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = 1; a.single = 1; a.ref_xy = d_ref; a.n_ref = n_ref; a.out = d_out;
@@ -601,7 +912,11 @@ void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const
     a.N = N; a.ds = ds; a.mcs = mcs; a.d0 = d0; a.rot_range = range3[2]; a.max_range = 15.0;
     a.sel_x = d_sel_x; a.sel_y = d_sel_y; a.n_sel = n_sel; a.n_coarse_rot = ncr; a.cap_sel = cap_sel;
     a.cell_off = 0.5;
+    a.ndt = v.ndt_refine; a.ndt_nc = ndt_cells(mcs); a.ndt_max_iter = 500;
+    const bool ndt = a.ndt && a.ndt_nc >= 2 && d_ndt_occ;
+    if (ndt) { a.ndt_occ = d_ndt_occ; a.ndt_aux = d_ndt_aux; }
     launch_match(v, a, 1, lds, s);
+    if (ndt) launch_ndt(v, a, 1, s);
 }
 
 }  // namespace rbpf

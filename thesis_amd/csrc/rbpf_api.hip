@@ -94,6 +94,7 @@ int rbpf_default_config(rbpf_config* c) {
     c->resample_spread = 200.0;  // main.py:50
     c->vel_noise[0] = 0.02; c->vel_noise[1] = 0.01; c->vel_noise[2] = 0.2; c->vel_noise[3] = 0.02;  // Freid101IMUData.py:51-55
     c->device = 0;
+    c->ndt_refine = 1;           // matchScanCustom.m:32-50 runs its second stage on every valid grid match
     c->seed = 42;
     return RBPF_OK;
 }
@@ -114,6 +115,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     if (c.n_samples < 1 || c.n_samples > 32) return fail(nullptr, RBPF_EINVAL, "n_samples must be in 1..32");
     if (c.max_beams < 1 || c.max_beams > 4095) return fail(nullptr, RBPF_EINVAL, "max_beams must be in 1..4095");
     if (c.lattice_radius < 0 || c.lattice_radius > 3) return fail(nullptr, RBPF_EINVAL, "lattice_radius must be in 0..3");
+    if (c.ndt_refine < 0 || c.ndt_refine > 2) return fail(nullptr, RBPF_EINVAL, "ndt_refine must be 0, 1 or 2");
     if (!(c.cell_size > 0) || c.tile_len_m < 1) return fail(nullptr, RBPF_EINVAL, "cell_size/tile_len_m");   // gridmap.py:29
     const int dim = (int)llround((double)c.tile_len_m / c.cell_size);                                        // gridmap.py:31
     if (dim < WIN || dim > 4096 || dim % 16 != 0) return fail(nullptr, RBPF_EINVAL, "tile dimension must be a multiple of 16 in 128..4096 cells");
@@ -218,7 +220,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             }
         }
         ALLOC(h, v.upd_pose, 3 * P);
-        ALLOC(h, v.stats, 16); ALLOC(h, v.err, 1);
+        ALLOC(h, v.stats, ST_COUNT); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
         ALLOC(h, h->d_did_early, 1);
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
@@ -230,12 +232,17 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             v.mu_mode = (mk && std::string(mk) == "window") ? 1 : 0;
             const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
             v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
+            v.ndt_refine = h->cfg.ndt_refine;
         }
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
         if (raycast_lds_bytes(c.max_beams, v.reach) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
         match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
         h->mlds = match_lds_bytes(h->mN, c.max_beams, match_max_coarse(h->mncr, 0.7, h->mmcs));
         if (h->mlds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this cell_size");
+        if (c.ndt_refine && ndt_cells(h->mmcs) >= 2) {         // the matcher hands its staged field to the NDT kernel
+            if (ndt_lds_bytes(h->mN, c.max_beams) > 160 * 1024) return fail(h, RBPF_EINVAL, "NDT stage: matcher region does not fit in LDS");
+            ALLOC(h, v.ndt_occ, P * (size_t)h->mN * (h->mN / 32)); ALLOC(h, v.ndt_aux, 5 * P);
+        }
         ALLOC(h, h->d_match, 13 * P); ALLOC(h, h->d_bad, P); ALLOC(h, h->d_guess_full, P * (size_t)c.n_samples * 3);
         {
             ResampleBuffers& r = h->rs;
@@ -247,7 +254,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipMemset(v.pool, 0, (size_t)v.pool_tiles * cells));
         HIP_TRY(h, hipMemset(v.px, 0, P * 8)); HIP_TRY(h, hipMemset(v.py, 0, P * 8)); HIP_TRY(h, hipMemset(v.pth, 0, P * 8));
         HIP_TRY(h, hipMemset(v.cov, 0, 9 * P * 8));
-        HIP_TRY(h, hipMemset(v.stats, 0, 128)); HIP_TRY(h, hipMemset(v.err, 0, 4));
+        HIP_TRY(h, hipMemset(v.stats, 0, ST_COUNT * 8)); HIP_TRY(h, hipMemset(v.err, 0, 4));
         // robot.py:20-28 / hybridmap.py:70: weight 1.0, one empty tile centred (0,0) per particle
         std::vector<double> w(P, 1.0);
         HIP_TRY(h, hipMemcpy(v.weight, w.data(), P * 8, hipMemcpyHostToDevice));
@@ -317,7 +324,7 @@ int rbpf_set_profiling(rbpf_handle* h, int on) {
     if (!h) return RBPF_EINVAL;
     h->profiling = on != 0;
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) h->ring_n[k] = 0;
-    HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, 16 * sizeof(unsigned long long), h->stream));   // counters restart
+    HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, ST_COUNT * sizeof(unsigned long long), h->stream));   // counters restart
     return RBPF_OK;
 }
 
@@ -340,7 +347,7 @@ int rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t ca
 
 int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     if (!h || !out) return RBPF_EINVAL;
-    unsigned long long st[16];
+    unsigned long long st[ST_COUNT];
     int32_t top = 0;
     HIP_TRY(h, hipMemcpyAsync(st, h->v.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&top, h->v.free_top, 4, hipMemcpyDeviceToHost, h->stream));
@@ -352,6 +359,7 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.resample_copies = st[ST_COPIES]; c.bytes_copied = st[ST_COPY_BYTES];
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
     c.window_fallbacks = st[ST_WINDOW_FALLBACKS];
+    c.ndt_runs = st[ST_NDT_RUNS]; c.ndt_evaluations = st[ST_NDT_EVALS]; c.ndt_accepted = st[ST_NDT_ACCEPTED];
     for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];
     // diagnostic slot: four 16-bit tallies of whole-fan fallback reasons, or the eighth phase stamp of a -DRBPF_STAMPS build
     c.cells_gathered = st[15] ? st[15] : st[ST_FALLBACK_REASONS];
@@ -562,17 +570,21 @@ int rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const
     if (lds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this resolution");
     std::vector<float> sel(2 * (size_t)h->cfg.max_beams, 0.f);
     for (int i = 0; i < n_curr; ++i) { sel[i] = (float)curr_xy[2 * i]; sel[h->cfg.max_beams + i] = (float)curr_xy[2 * i + 1]; }
-    double *d_ref = nullptr, *d_out = nullptr;
+    double *d_ref = nullptr, *d_out = nullptr, *d_aux = nullptr; uint32_t* d_occ = nullptr;
     HIP_TRY(h, hipMalloc((void**)&d_ref, std::max<size_t>((size_t)n_ref, 1) * 16));
     HIP_TRY(h, hipMalloc((void**)&d_out, 13 * 8));
+    if (c.ndt_refine && ndt_cells(mcs) >= 2 && ndt_lds_bytes(N, h->cfg.max_beams) <= 160 * 1024) {
+        HIP_TRY(h, hipMalloc((void**)&d_occ, (size_t)N * (N / 32) * 4));
+        HIP_TRY(h, hipMalloc((void**)&d_aux, 5 * 8));
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, h->stream));
     if (n_ref) HIP_TRY(h, hipMemcpyAsync(d_ref, ref_xy, (size_t)n_ref * 16, hipMemcpyHostToDevice, h->stream));
     launch_match_single(h->v, d_ref, n_ref, guess3, pose_range3, h->d_tmp_sel, h->d_tmp_sel + h->cfg.max_beams, n_curr, d_out,
-                        N, ds, mcs, d0, ncr, h->cfg.max_beams, lds, h->stream);
+                        N, ds, mcs, d0, ncr, h->cfg.max_beams, lds, d_occ, d_aux, h->stream);
     double out[13];
     HIP_TRY(h, hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, h->stream));
     int rc = check_device_error(h);
-    (void)hipFree(d_ref); (void)hipFree(d_out);
+    (void)hipFree(d_ref); (void)hipFree(d_out); (void)hipFree(d_occ); (void)hipFree(d_aux);
     if (rc) return rc;
     // matchScanCustom.m:19,52-57 validity gate
     const double PI = 3.141592653589793;

@@ -53,6 +53,8 @@ struct DevView {
     double*  upd_pose;                 // [3][P] poses used by the current map update
     int32_t* mu_fallback;              // [P] 1 = the whole-fan map update gave the particle back to the window kernel
     int mu_mode;                       // 0 = whole-fan kernel when the layout allows it, 1 = 128x128 windows only
+    uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
+    int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
     int match_stage_slow;              // 1 = the matcher stages its field bit by bit (RBPF_MATCH_STAGE=slow; the check of the fast path)
     unsigned long long* stats;         // [8] device counters
     int32_t* err;                      // [1] sticky device error code
@@ -68,7 +70,9 @@ struct ResampleBuffers {
 };
 
 enum { ST_RAY_CELLS = 0, ST_CELLS_WRITTEN = 1, ST_GATHERS = 2, ST_SLOW_CELLS = 3,
-       ST_COPIES = 4, ST_COPY_BYTES = 5, ST_WINDOW_FALLBACKS = 6, ST_FALLBACK_REASONS = 7 };
+       ST_COPIES = 4, ST_COPY_BYTES = 5, ST_WINDOW_FALLBACKS = 6, ST_FALLBACK_REASONS = 7,
+       /* 8..15: phase stamps of a -DRBPF_STAMPS build */
+       ST_NDT_RUNS = 16, ST_NDT_EVALS = 17, ST_NDT_ACCEPTED = 18, ST_COUNT = 24 };
 
 }  // namespace rbpf
 
@@ -145,13 +149,15 @@ void launch_propose_weight(const DevView& v, const double* d_match, const double
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s);
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s);
 size_t match_lds_bytes(int N, int B, int n_coarse);
+size_t ndt_lds_bytes(int N, int B);
+int ndt_cells(double mcs);
 void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot);
 int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs);
 void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
                             double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, hipStream_t s);
 void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
                          const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
-                         double d0, int ncr, int cap_sel, size_t lds, hipStream_t s);
+                         double d0, int ncr, int cap_sel, size_t lds, uint32_t* d_ndt_occ, double* d_ndt_aux, hipStream_t s);
 void launch_match_inputs(const DevView& v, int particle, const double* guess3, double* d_all_curr, int* d_counts,
                          uint32_t* d_mask, int* d_row_cnt, double* d_ref, int cap_ref, double* d_curr, int win,
                          double match_max, hipStream_t s);

@@ -261,7 +261,7 @@ class ParticleEngine:
             if int(d["version"]) != cls.CHECKPOINT_VERSION:
                 raise ValueError("unknown checkpoint version")
             cfg = json.loads(str(d["config"]))
-            skip = {"n_particles", "n_samples", "max_beams", "cell_size", "tile_len_m", "lattice_radius", "pool_tiles", "device", "seed", "reserved0"}
+            skip = {"n_particles", "n_samples", "max_beams", "cell_size", "tile_len_m", "lattice_radius", "pool_tiles", "device", "seed"}
             over = {k: (tuple(v) if k == "vel_noise" else v) for k, v in cfg.items() if k not in skip}
             e = cls(cfg["n_particles"], n_samples=cfg["n_samples"], max_beams=cfg["max_beams"], cell_size=cfg["cell_size"],
                     tile_len_m=cfg["tile_len_m"], lattice_radius=cfg["lattice_radius"], pool_tiles=cfg["pool_tiles"],
