@@ -53,7 +53,7 @@ def parse():
 class Runner:
     """The reference's event loop body for accepted scans, on one rank."""
 
-    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None, device=0, ndt=0):
+    def __init__(self, P, B, cell_size, log, rank=0, world=1, shard=None, device=0, ndt=NDT_DEFAULT):
         from thesis_amd.engine import ParticleEngine
         self.P, self.B, self.rank, self.world = P, B, rank, world
         self.angles, self.ranges, self.odo, self.true_poses = log
@@ -109,7 +109,7 @@ class Runner:
         self.frame += 1
 
 
-KERNEL_NAMES = {"raycast": "rbpf::map_update_fan_kernel", "match": "rbpf::match_kernel",
+KERNEL_NAMES = {"raycast": "rbpf::map_update_fan_kernel", "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
                 "weight": "rbpf::propose_weight_kernel", "resample": "rbpf::resample_copy_kernel"}
 
 
@@ -239,19 +239,19 @@ def main():
     P_total = args.particles * world
     value = P_total * args.steps / elapsed
     # ---- roofline of the dominant kernel, HIP events recorded inside the timed region ------------------
-    kms = {k: run.e.kernel_ms(k) for k in ("raycast", "weight", "resample", "match", "ray_setup")}
+    kms = {k: run.e.kernel_ms(k) for k in ("raycast", "weight", "resample", "match", "ndt")}
     mean_ms = {k: (float(v.mean()) if len(v) else 0.0) for k, v in kms.items()}
     c = run.e.counters()
     n_upd = max(1, args.steps)
     W_per_particle = c["cells_written"] / (n_upd * args.particles)          # |W|, unique cells written per particle-update
     cells_per_particle = c["ray_cells_visited"] / (n_upd * args.particles)
-    dominant = max(("raycast", "weight", "match", "resample"), key=lambda k: mean_ms[k])
+    dominant = max(("raycast", "weight", "match", "ndt", "resample"), key=lambda k: mean_ms[k])
     # algorithmic bytes with 4-byte cells.  Per particle-update:
     #   ray-cast kernel   4|W| read + 4|W| write
     #   weighting kernel  4|R_w|, R_w = cells under the K*B sample endpoints (<= K*B, ~B distinct)
     #   match kernel      4 * region cells (the occupancy region staged once per particle)
     alg_bytes = {"raycast": 8.0 * W_per_particle, "weight": 4.0 * args.beams * 2,
-                 "match": 4.0 * 480 * 480, "resample": 0.0}
+                 "match": 4.0 * 480 * 480, "ndt": 4.0 * 480 * 480, "resample": 0.0}
     if c["resample_copies"]:
         alg_bytes["resample"] = 4.0 * c["bytes_copied"] / (n_upd * args.particles)
     ach = alg_bytes[dominant] * args.particles / (mean_ms[dominant] * 1e-3) / 1e9 if mean_ms[dominant] > 0 else 0.0
@@ -297,7 +297,8 @@ def main():
             big.step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        km = {k: float(big.e.kernel_ms(k).mean()) for k in ("raycast", "weight", "resample", "match", "ray_setup")}
+        km = {k: (float(x.mean()) if len(x) else 0.0)
+              for k, x in ((k, big.e.kernel_ms(k)) for k in ("raycast", "weight", "resample", "match", "ndt"))}
         cb = big.e.counters()
         Wb = cb["cells_written"] / (nb * 10240)
         out["target_10k"] = {"particles": 10240, "value": 10240 * nb / dt, "ms_per_step": 1e3 * dt / nb,

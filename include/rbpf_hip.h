@@ -114,8 +114,8 @@ int  rbpf_synchronize(rbpf_handle* h);
 int  rbpf_get_counters(rbpf_handle* h, rbpf_counters* out);
 int  rbpf_set_profiling(rbpf_handle* h, int on);     /* per-kernel HIP events; resets the rings */
 /* durations (ms) of the launches recorded since rbpf_set_profiling, HIP events on the handle's stream;
- * which: 0 ray-cast map-update kernel, 1 proposal/weighting kernel, 2 resample kernels, 3 scan-match kernel,
- * 4 unused.  Synchronises the stream. */
+ * which: 0 ray-cast map-update kernel, 1 proposal/weighting kernel, 2 resample kernels, 3 scan-match grid stage,
+ * 4 scan-match NDT stage.  Synchronises the stream. */
 int  rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t cap, int32_t* n_out);
 
 /* ---- a1: scan geometry (Scan.__init__, lidar.py:76-80) ------------------------------------ */

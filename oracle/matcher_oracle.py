@@ -30,7 +30,8 @@ NDT_MAX_ITER = 500        # matchScanCustom.m:36
 NDT_MIN_POINTS = 3
 NDT_EIG_FLOOR = 1e-3
 LAM0, LAM_MIN, LAM_MAX = 1e-3, 1e-7, 1e7
-TOL_T, TOL_R = 5e-3, 1e-4     # convergence: proposed step below 0.005 cells (0.25 mm at 0.05 m) and 1e-4 rad
+TOL_T, TOL_R = 1e-2, 2e-4     # convergence: proposed step below 0.01 cells (0.5 mm at 0.05 m) and 2e-4 rad
+LAM_UP, LAM_DOWN = 100.0, 0.1  # damping after a rejected / an accepted trial
 
 
 def _cell_stats(occ: np.ndarray, u0: np.ndarray, w0: np.ndarray, nc: int):
@@ -167,9 +168,9 @@ def ndt_refine(occ: np.ndarray, pts_all: np.ndarray, start, nc: int, ox: int, oy
         if trial[0] < cur[0]:
             p = p + d
             cur = trial
-            lam = max(lam * 0.1, LAM_MIN)
+            lam = max(lam * LAM_DOWN, LAM_MIN)
         else:
-            lam *= 10.0
+            lam *= LAM_UP
             if lam > LAM_MAX:
                 break
     return p, -ndt_eval(occ, pts_all, p, nc, ox, oy, single)[0], evals

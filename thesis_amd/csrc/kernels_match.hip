@@ -21,7 +21,8 @@
 //   ndt      (rbpf_config.ndt_refine) the second stage of matchScanCustom.m:32-50: Normal Distributions Transform
 //            (Biber & Strasser 2003, the algorithm MATLAB's matchScans documents) with the call site's CellSize 0.1 m
 //            and MaxIterations 500, started from the correlative optimum and accepted by the reference's rule
-//            (valid pose and 2 * ndtScore > gridScore; the covariance stays the grid one).  Restated on the CPU in
+//            (valid pose and 2 * ndtScore > gridScore; the covariance stays the grid one).  Its own kernel
+//            (ndt_kernel) on the occupancy field match_kernel staged.  Restated on the CPU in
 //            oracle/matcher_oracle.py; MATLAB's own numerics stay unpinned.
 #include <limits.h>
 #include <string.h>
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
                 ndt_p[0] = tx; ndt_p[1] = ty; ndt_p[2] = tt;
                 lam = fmax(lam * 0.1, 1e-7);
             } else {
-                lam *= 10.0;
+                lam *= 100.0;                  // a rejected trial: the quadratic model is off (a cell boundary), damp hard
                 if (lam > 1e7) go = false;
             }
             ++evals;
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
                 bool have = false;
                 while (lam <= 1e7 && !(have = ndt_lm_step(cur, lam, step))) lam *= 10.0;
                 if (!have) go = false;
-                else if (fmax(fabs(step[0]), fabs(step[1])) < 5e-3 && fabs(step[2]) < 1e-4) go = false;   // converged: step below 0.005 cells, 1e-4 rad
+                else if (fmax(fabs(step[0]), fabs(step[1])) < 1e-2 && fabs(step[2]) < 2e-4) go = false;   // converged: step below 0.01 cells, 2e-4 rad
                 else { s_trial[0] = ndt_p[0] + step[0]; s_trial[1] = ndt_p[1] + step[1]; s_trial[2] = ndt_p[2] + step[2]; }
             }
             if (!go) { s_trial[0] = ndt_p[0]; s_trial[1] = ndt_p[1]; s_trial[2] = ndt_p[2]; }
@@ -887,8 +888,10 @@ static void launch_ndt(const DevView& v, const MatchArgs& a, int grid, hipStream
     hipLaunchKernelGGL(ndt_kernel, dim3(grid), dim3(NBLOCK), lds, s, v, a);
 }
 
-void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
-                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, hipStream_t s) {
+// stage 1: the grid search (match_kernel); stage 2: the NDT refinement (ndt_kernel) -- two calls so that the host can
+// time them apart.  Returns whether the NDT stage is active for this configuration.
+bool launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
+                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, int stage, hipStream_t s) {
     MatchArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = mode; a.single = 0; a.ref_xy = d_ref; a.n_ref = n_ref; a.out = d_out;
@@ -898,8 +901,9 @@ void launch_match_particles(const DevView& v, int mode, const double* d_ref, int
     a.ndt = v.ndt_refine; a.ndt_nc = ndt_cells(mcs); a.ndt_max_iter = 500;
     const bool ndt = a.ndt && a.ndt_nc >= 2 && v.ndt_occ;
     if (ndt) { a.ndt_occ = v.ndt_occ; a.ndt_aux = v.ndt_aux; }
-    launch_match(v, a, v.P, lds, s);
-    if (ndt) launch_ndt(v, a, v.P, s);
+    if (stage == 1) launch_match(v, a, v.P, lds, s);
+    if (stage == 2 && ndt) launch_ndt(v, a, v.P, s);
+    return ndt;
 }
 
 void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,

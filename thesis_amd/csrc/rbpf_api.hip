@@ -496,9 +496,15 @@ static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, 
         h->ring_last.submitted(h->stream);
     }
     h->prof_begin(3);
-    launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
-                           h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, h->stream);
+    const bool ndt = launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
+                                            h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 1, h->stream);
     h->prof_end(3);
+    if (ndt) {
+        h->prof_begin(4);
+        launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
+                               h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 2, h->stream);
+        h->prof_end(4);
+    }
     HIP_TRY(h, hipGetLastError());
     return RBPF_OK;
 }

@@ -111,7 +111,7 @@ struct rbpf_handle {
     int32_t* d_gT = nullptr; size_t d_gT_cap = 0; int32_t* d_gidx = nullptr; size_t d_gidx_cap = 0;
     int32_t* d_i32 = nullptr; size_t d_i32_cap = 0; unsigned char* d_jobs = nullptr; size_t d_jobs_cap = 0;
     // profiling: a ring of HIP-event pairs per kernel family, recorded on the handle's stream
-    static const int N_KERN = 5, RING = 512;        // 0 ray-cast windows, 1 propose/weight, 2 resample, 3 match, 4 ray setup
+    static const int N_KERN = 5, RING = 512;        // 0 map update, 1 propose/weight, 2 resample, 3 match (grid stage), 4 match (NDT stage)
     std::vector<hipEvent_t> ring[N_KERN][2];
     int ring_n[N_KERN] = {0, 0, 0, 0, 0};
     hipEvent_t prof_begin(int k) { if (!profiling) return nullptr; hipEvent_t e = ring[k][0][ring_n[k] % RING]; (void)hipEventRecord(e, stream); return e; }
@@ -153,8 +153,8 @@ size_t ndt_lds_bytes(int N, int B);
 int ndt_cells(double mcs);
 void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot);
 int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs);
-void launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
-                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, hipStream_t s);
+bool launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
+                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, int stage, hipStream_t s);
 void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
                          const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
                          double d0, int ncr, int cap_sel, size_t lds, uint32_t* d_ndt_occ, double* d_ndt_aux, hipStream_t s);

@@ -93,7 +93,7 @@ class ParticleEngine:
     def set_profiling(self, on: bool):
         self._check(self._lib.rbpf_set_profiling(self._h, int(on)))
 
-    KERNELS = {"raycast": 0, "weight": 1, "resample": 2, "match": 3, "ray_setup": 4}
+    KERNELS = {"raycast": 0, "weight": 1, "resample": 2, "match": 3, "ndt": 4}
 
     def kernel_ms(self, which) -> np.ndarray:
         """Per-launch durations (ms, HIP events on the engine's stream) since set_profiling(True)."""
