@@ -834,35 +834,40 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             const int ngr = g_hi - g_lo + 1, items = (wx_hi - wx_lo + 1) * ngr;
             int8_t* __restrict__ tile_base = v.pool + (size_t)tile * v.dim * v.dim;
             int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
-            auto write_back = [&](int it) {
+            // an item in two halves, so that a lane can have the loads of two groups in flight before it computes either
+            struct Item { uint32_t n[8]; uint32_t pre[8]; uint32_t* g_ptr; int row, col; bool live; };
+            auto fetch = [&](int it, Item& I) {
+                I.live = false;
+                if (it >= items) return;
                 const int rr = it / ngr, gg = it - rr * ngr;
                 const int wx = wx_lo + rr, Gy = g_lo + gg;
-                const int row = wx + Ux0 - a * v.dim, col = 32 * Gy - bt * v.dim;
+                I.row = wx + Ux0 - a * v.dim; I.col = 32 * Gy - bt * v.dim;
                 const int wy_first = 32 * Gy - Uy0al;                              // multiple of 4, may be negative
-                uint32_t n[8];
                 uint32_t any = 0;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
                     const int wyw = wy_first + 4 * w;
-                    n[w] = (wyw >= 0 && wyw < stride) ? cnt[(wx * stride + wyw) >> 2] : 0u;
-                    any |= n[w];
+                    I.n[w] = (wyw >= 0 && wyw < stride) ? cnt[(wx * stride + wyw) >> 2] : 0u;
+                    any |= I.n[w];
                 }
                 if (!any) return;
-                uint32_t* const g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)row * v.dim + col);
-                uint32_t pre[8];
-                {
-                    const uint4 q0 = reinterpret_cast<const uint4*>(g_ptr)[0], q1 = reinterpret_cast<const uint4*>(g_ptr)[1];
-                    pre[0] = q0.x; pre[1] = q0.y; pre[2] = q0.z; pre[3] = q0.w; pre[4] = q1.x; pre[5] = q1.y; pre[6] = q1.z; pre[7] = q1.w;
-                }
+                I.live = true;
+                I.g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)I.row * v.dim + I.col);
+                const uint4 q0 = reinterpret_cast<const uint4*>(I.g_ptr)[0], q1 = reinterpret_cast<const uint4*>(I.g_ptr)[1];
+                I.pre[0] = q0.x; I.pre[1] = q0.y; I.pre[2] = q0.z; I.pre[3] = q0.w; I.pre[4] = q1.x; I.pre[5] = q1.y; I.pre[6] = q1.z; I.pre[7] = q1.w;
+            };
+            auto finish = [&](const Item& I) {
+                if (!I.live) return;
                 // Four cells per 32-bit word at a time (bytes never carry into each other: cells lie in [vmin, vmax],
                 // hit counts below 96, sat * |emp| below 128): O = cell - vmin, R = max(O - |emp| * min(n, sat), 0).
-                uint32_t occ = 0, touched = 0;
+                uint32_t occ = 0, touched = 0, out[8];
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
-                    const uint32_t Ob = (pre[w] ^ 0x80808080u) - kb1;                       // cells biased to [0, vmax - vmin]
+                    const uint32_t Ob = (I.pre[w] ^ 0x80808080u) - kb1;                     // cells biased to [0, vmax - vmin]
                     uint32_t R = Ob;
-                    if (n[w]) {
-                        const uint32_t nw = n[w], n7 = nw & 0x7F7F7F7Fu;
+                    out[w] = I.pre[w];
+                    if (I.n[w]) {
+                        const uint32_t nw = I.n[w], n7 = nw & 0x7F7F7F7Fu;
                         const uint32_t ge = (n7 + sadd) & 0x80808080u;                      // fields >= sat
                         const uint32_t gem = ge | (ge - (ge >> 7));
                         const uint32_t m = (satb & gem) | (n7 & ~gem);                      // min(n, sat)
@@ -875,19 +880,23 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                             const uint32_t flm = fl | (fl - (fl >> 7));
                             R = (n7 & flm) | (R & ~flm);
                         }
-                        g_ptr[w] = (R + kb1) ^ 0x80808080u;
+                        out[w] = (R + kb1) ^ 0x80808080u;
                         const uint32_t nz = ((n7 + 0x7F7F7F7Fu) | nw) & 0x80808080u;        // fields that are not zero
                         touched |= __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false) << (4 * w);
                     }
                     occ |= __builtin_amdgcn_udot4(((R + oadd) & 0x80808080u) >> 7, 0x08040201u, 0u, false) << (4 * w);   // cell > thr
                 }
+                // the whole group goes back in two 16-byte stores (untouched words keep their value; this workgroup is
+                // the tile's only writer)
+                reinterpret_cast<uint4*>(I.g_ptr)[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<uint4*>(I.g_ptr)[1] = make_uint4(out[4], out[5], out[6], out[7]);
                 my_written += __popc(touched);
-                by0 = min(by0, col + __ffs(touched) - 1); by1 = max(by1, col + 31 - __clz(touched));
-                v.occ[((size_t)tile * v.dim + row) * v.ow + (col >> 5)] = occ;
-                bx0 = min(bx0, row); bx1 = max(bx1, row);
+                by0 = min(by0, I.col + __ffs(touched) - 1); by1 = max(by1, I.col + 31 - __clz(touched));
+                v.occ[((size_t)tile * v.dim + I.row) * v.ow + (I.col >> 5)] = occ;
+                bx0 = min(bx0, I.row); bx1 = max(bx1, I.row);
             };
-            // waves fetch 64 items at a time: groups without a touched cell cost next to nothing, so a static split
-            // would leave some waves with most of the work
+            // waves fetch 128 items at a time, two per lane: groups without a touched cell cost next to nothing, so a
+            // static split would leave some waves with most of the work
             const int ci = combo++;                                                // uniform over the workgroup
             if (ci < 8) {
                 while (true) {
@@ -895,10 +904,12 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
                     if (lane == 0) base = atomicAdd(&s_pq[ci], 64);
                     base = UNI(base);
                     if (base >= items) break;
-                    if (base + lane < items) write_back(base + lane);
+                    Item A;
+                    fetch(base + lane, A);
+                    finish(A);
                 }
             } else {
-                for (int it = tid; it < items; it += FB) write_back(it);
+                for (int it = tid; it < items; it += FB) { Item A; fetch(it, A); finish(A); }
             }
 
             bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
