@@ -271,8 +271,12 @@ def main():
            "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "int8 map cells (lattice log-odds), f64 poses/weights", "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[1]: room16 synthetic, {args.particles} particles/GPU, "
-                                  f"{args.beams} beams, {args.cell_size} m grid, K=30 samples, resample every step",
+           "config": {"workload": ("BASELINE configs[1]" if (args.particles, args.beams, args.cell_size) == (1024, 1081, 0.05)
+                                   else "non-default size") +
+                                  f": room16 synthetic, {args.particles} particles/GPU, "
+                                  f"{args.beams} beams, {args.cell_size} m grid, K=30 samples, "
+                                  + ("both matcher stages, " if args.ndt else "grid matcher stage only, ") +
+                                  "resample every step",
                       "particles_per_gpu": args.particles, "beams": args.beams, "cell_size": args.cell_size,
                       "parallelism": f"particles sharded x{world}"},
            "roofline": roofline}
