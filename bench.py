@@ -185,8 +185,24 @@ def cpu_baseline(log, B, cell_size, seconds=12.0):
                       f"scan matcher excluded (MATLAB, not timeable); single core: {1.0 / per_pu:.1f}/s"}
 
 
+def _finite(x):
+    """JSON has no NaN/Infinity: non-finite floats become null."""
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, float) and not np.isfinite(x):
+        return None
+    return x
+
+
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON: whatever libraries print there (RCCL's version banner on the first
+    # collective, for one) is sent to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -311,7 +327,8 @@ def main():
         big.e.close()
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(log, args.beams, args.cell_size)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(_finite(out), allow_nan=False) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
