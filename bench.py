@@ -179,10 +179,24 @@ def cpu_baseline(log, B, cell_size, seconds=12.0):
         list(ex.map(work, [n_each] * cores))
     wall = time.perf_counter() - t0
     total = cores * n_each * n_steps
+    # the loop-faithful Python restatement (the form the reference itself has), one thread, a few particle-updates
+    py_n = 2
+    hm = orc.OracleHybridMap(cell_size)
+    hm.update(tuple(poses[0]), sx[0], sy[0])
+    g = poses[1] + rng.normal(0, 0.01, size=(py_n, K, 3))
+    t0 = time.perf_counter()
+    for i in range(py_n):
+        w = orc.generate_sample_weight(hm, g[i], sx[1], sy[1], np.ones(K))
+        mean, _, _ = orc.proposal_moments(g[i], w)
+        hm.update(tuple(float(x) for x in mean), sx[1], sy[1])
+    py_rate = py_n / (time.perf_counter() - t0)
     return {"value": total / wall, "unit": "particle-updates/s", "cores": cores, "kind": "port",
             "sample": f"{total} particle-updates ({cores} threads x {n_each} particles x {n_steps} scans, B={B}, "
                       f"cs={cell_size}): C restatement of Robot.map_update (weighting + moments + ray-cast), "
-                      f"scan matcher excluded (MATLAB, not timeable); single core: {1.0 / per_pu:.1f}/s"}
+                      f"scan matcher excluded (MATLAB, not timeable); single core: {1.0 / per_pu:.1f}/s",
+            "python_port_single_thread": {"value": py_rate, "unit": "particle-updates/s", "cores": 1,
+                                          "sample": f"{py_n} particle-updates of oracle/rbpf_oracle.py (the reference's own "
+                                                    "loop structure: Robot._generate_sample_weight + moments + HybridMap.update)"}}
 
 
 def _finite(x):
