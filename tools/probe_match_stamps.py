@@ -7,7 +7,7 @@ from bench import Runner, PERIOD_S
 from thesis_amd.datasets import synthetic
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 10240
 log = synthetic.make_log(16, 1081, period=PERIOD_S)
-r = Runner(P, 1081, 0.05, log)
+r = Runner(P, 1081, 0.05, log, ndt=0)          # with the NDT stage on, its kernel owns the stamp slots (tools/probe_ndt_stamps.py)
 for _ in range(5):
     r.step()
 names = ["setup+zero", "field", "dilate+pool", "coarse", "fine", "score+cov", "colmap", "spare"]
