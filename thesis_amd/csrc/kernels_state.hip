@@ -99,6 +99,19 @@ __global__ void last_scan_kernel(DevView v, int particle, double* __restrict__ o
     out_xy[2 * b + 1] = (sn * x + cs * y) + v.py[particle];
 }
 
+// The per-step scan block (17 KB) is pulled out of pinned, device-mapped host memory by a kernel: a DMA copy of this
+// size spends ~20 us in the copy engine's scheduling, during which the stream's next kernel cannot start.
+__global__ void ingest_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s) {
+    const int n16 = (int)((bytes + 15) / 16);
+    hipLaunchKernelGGL(ingest_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(mapped_src),
+                       static_cast<uint4*>(d_dst), n16);
+}
+
 void launch_last_scan(const DevView& v, int particle, double* d_out_xy, hipStream_t s) {
     hipLaunchKernelGGL(last_scan_kernel, dim3((v.B + 255) / 256), dim3(256), 0, s, v, particle, d_out_xy);
 }

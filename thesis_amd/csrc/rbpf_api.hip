@@ -407,7 +407,11 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
     }
     DevView& v = h->v;
     v.n_msel = nm; v.n_asel = na;
-    HIP_TRY(h, hipMemcpyAsync(h->d_scan, slot, h->scan_bytes, hipMemcpyHostToDevice, h->stream));   // pinned: no stream drain
+    {   // pinned and device-mapped: a kernel pulls the block over (no copy-engine latency in the stream); DMA otherwise
+        void* mapped = nullptr;
+        if (hipHostGetDevicePointer(&mapped, slot, 0) == hipSuccess && mapped) launch_ingest(mapped, h->d_scan, h->scan_bytes, h->stream);
+        else { (void)hipGetLastError(); HIP_TRY(h, hipMemcpyAsync(h->d_scan, slot, h->scan_bytes, hipMemcpyHostToDevice, h->stream)); }
+    }
     h->ring_scan.submitted(h->stream);
     v.B = B;
     h->have_scan = true;

@@ -126,6 +126,7 @@ namespace rbpf {
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
 void launch_map_update_fused(const DevView& v, hipStream_t s);   // picks the kernel(s) below
+void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s);   // bytes rounded up to 16
 bool map_update_fan_available(const DevView& v);
 void launch_map_update_fan(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
