@@ -180,6 +180,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
                 // timing only: no system-scope fence when the event completes (it would flush the caches between the
                 // kernels it brackets and slow the very thing it measures)
                 for (auto& ev : h->ring[k][e]) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
+                h->begin_used[k].assign(rbpf_handle::RING, nullptr);
             }
         const size_t P = v.P, LL = (size_t)v.L * v.L, cells = (size_t)dim * dim;
         uint32_t* d_lut; ALLOC(h, d_lut, h->h_lut.size()); v.lut = d_lut;
@@ -324,6 +325,7 @@ int rbpf_set_profiling(rbpf_handle* h, int on) {
     if (!h) return RBPF_EINVAL;
     h->profiling = on != 0;
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) h->ring_n[k] = 0;
+    h->last_end = nullptr;
     HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, ST_COUNT * sizeof(unsigned long long), h->stream));   // counters restart
     return RBPF_OK;
 }
@@ -337,7 +339,7 @@ int rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t ca
     for (int i = 0; i < n && m < cap; ++i) {
         int slot = (first + i) % rbpf_handle::RING;
         float ms = 0;
-        if (hipEventElapsedTime(&ms, h->ring[which][0][slot], h->ring[which][1][slot]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventElapsedTime(&ms, h->begin_used[which][slot], h->ring[which][1][slot]) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (out_ms) out_ms[m] = ms;
         ++m;
     }
@@ -369,7 +371,7 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
             if (h->ring_n[k] == 0) continue;
             int slot = (h->ring_n[k] - 1) % rbpf_handle::RING;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, h->ring[k][0][slot], h->ring[k][1][slot]) == hipSuccess) *dst[k] = ms;
+            if (hipEventElapsedTime(&ms, h->begin_used[k][slot], h->ring[k][1][slot]) == hipSuccess) *dst[k] = ms;
         }
         (void)hipGetLastError();
     }
@@ -504,7 +506,7 @@ static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, 
                                             h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 1, h->stream);
     h->prof_end(3);
     if (ndt) {
-        h->prof_begin(4);
+        h->prof_begin_chained(4);
         launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
                                h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 2, h->stream);
         h->prof_end(4);
@@ -539,7 +541,7 @@ int rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_
         HIP_TRY(h, hipMemcpyAsync(h->d_guess_full, guesses, P * (size_t)v.K * 3 * 8, hipMemcpyHostToDevice, h->stream));
         d_g = h->d_guess_full;
     }
-    h->prof_begin(1);
+    if (!match_override && !guesses) h->prof_begin_chained(1); else h->prof_begin(1);     // right after the matcher's last kernel
     launch_propose_weight(v, h->d_match, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
     h->prof_end(1);
     HIP_TRY(h, hipGetLastError());

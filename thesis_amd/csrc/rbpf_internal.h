@@ -114,8 +114,12 @@ struct rbpf_handle {
     static const int N_KERN = 5, RING = 512;        // 0 map update, 1 propose/weight, 2 resample, 3 match (grid stage), 4 match (NDT stage)
     std::vector<hipEvent_t> ring[N_KERN][2];
     int ring_n[N_KERN] = {0, 0, 0, 0, 0};
-    hipEvent_t prof_begin(int k) { if (!profiling) return nullptr; hipEvent_t e = ring[k][0][ring_n[k] % RING]; (void)hipEventRecord(e, stream); return e; }
-    void prof_end(int k) { if (!profiling) return; (void)hipEventRecord(ring[k][1][ring_n[k] % RING], stream); ring_n[k]++; }
+    std::vector<hipEvent_t> begin_used[N_KERN];     // the event that marks a launch's start: its own, or the previous family's end
+    hipEvent_t last_end = nullptr;
+    void prof_begin(int k) { if (!profiling) return; hipEvent_t e = ring[k][0][ring_n[k] % RING]; (void)hipEventRecord(e, stream); begin_used[k][ring_n[k] % RING] = e; }
+    // the previous timed family ended right before this one starts (nothing enqueued in between): one record serves both
+    void prof_begin_chained(int k) { if (!profiling) return; if (!last_end) { prof_begin(k); return; } begin_used[k][ring_n[k] % RING] = last_end; }
+    void prof_end(int k) { if (!profiling) return; last_end = ring[k][1][ring_n[k] % RING]; (void)hipEventRecord(last_end, stream); ring_n[k]++; }
     rbpf::ResampleBuffers rs;
     rbpf_counters counters;
     unsigned long long scan_updates = 0;
