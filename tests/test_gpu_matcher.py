@@ -124,8 +124,9 @@ def test_builtin_matcher_failure_takes_nan_branch():
     e.close()
 
 
-def test_field_staging_fast_path_equals_bit_by_bit(monkeypatch):
-    """The matcher stages the particle's own map as funnel-shifted occupancy words plus the 'one cell lower' columns
+@pytest.mark.parametrize("cs", [0.05, 0.025])
+def test_field_staging_fast_path_equals_bit_by_bit(monkeypatch, cs):
+    """(0.025 m maps: a matcher cell is 2 x 2 map cells, the fast path works on 64-column windows.)  The matcher stages the particle's own map as funnel-shifted occupancy words plus the 'one cell lower' columns
     of the reference's index formula; RBPF_MATCH_STAGE=slow reads every bit through the index map instead.  Both
     must give the same match (pose, covariance, score) for particles on the irregular negative side of the map and
     next to a tile edge."""
@@ -143,7 +144,7 @@ def test_field_staging_fast_path_equals_bit_by_bit(monkeypatch):
             monkeypatch.setenv("RBPF_MATCH_STAGE", "slow")
         else:
             monkeypatch.delenv("RBPF_MATCH_STAGE", raising=False)
-        e = engine.ParticleEngine(P, max_beams=B, pool_tiles=64, seed=3)
+        e = engine.ParticleEngine(P, max_beams=B, pool_tiles=64, seed=3, cell_size=cs)
         e.set_state(poses=poses)
         e.set_scan(scans[0], ang)
         e.map_update(poses)

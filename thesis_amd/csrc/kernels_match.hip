@@ -186,6 +186,62 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         MSTAMP(6);
         // One region word (32 columns of one row) per lane.  A wave takes 16 rows x 4 adjacent words, so that the words
         // with many defect columns meet in few waves and the loads of a row stay contiguous.
+        if (a.ds == 2 && 2 * W <= 32 && !v.match_stage_slow) {
+            // Matcher cell = 2 x 2 map cells (0.025 m maps): a region word is 64 map columns of two map rows.  Same
+            // scheme as below on 64-bit windows, then neighbouring bit pairs are OR-ed and the even bits compressed.
+            for (int q = tid; q < N * W; q += MBLOCK) {
+                const int u = q / W, wv = q % W;
+                const int e0 = colmap[wv * 64], e1 = colmap[wv * 64 + 32];
+                const bool fast2 = !((s_slowg >> (2 * wv)) & 3u) && e0 >= 0 && e1 >= 0 && (e0 >> 12) == (e1 >> 12);
+                uint32_t bits = 0;
+                if (fast2) {
+                    const int lat = e0 >> 12;
+                    const int c0 = (oy * 2 + wv * 64) - (lat - v.R) * v.dim + v.dim / 2;      // storage column of the first map column
+                    const int cy = max(c0 - 1, 0), wi = cy >> 5, sft = c0 - (wi << 5);         // 0..32
+                    const unsigned long long d64 = ((unsigned long long)s_def[2 * wv + 1] << 32) | s_def[2 * wv];
+                    unsigned long long acc = 0;
+                    for (int du = 0; du < 2; ++du) {
+                        const uint32_t rb = rowbase[u * 2 + du];
+                        if (rb == 0xFFFFFFFFu) continue;
+                        const int t = s_tab[(rb >> 24) * v.L + lat];
+                        if (t < 0) continue;
+                        const uint32_t* row = v.occ + ((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow;
+                        const uint32_t w0 = row[wi], w1 = wi + 1 < v.ow ? row[wi + 1] : 0u, w2 = wi + 2 < v.ow ? row[wi + 2] : 0u,
+                                       w3 = wi + 3 < v.ow ? row[wi + 3] : 0u;
+                        const unsigned long long A = ((unsigned long long)w1 << 32) | w0, B = ((unsigned long long)w3 << 32) | w2;
+                        unsigned long long b64 = sft == 0 ? A : (A >> sft) | (B << (64 - sft));
+                        if (d64) {                                                              // columns stored one cell lower
+                            const int s1 = sft - 1;
+                            const unsigned long long below = s1 < 0 ? A << 1 : s1 == 0 ? A : (A >> s1) | (B << (64 - s1));
+                            b64 = (b64 & ~d64) | (below & d64);
+                        }
+                        acc |= b64;
+                    }
+                    unsigned long long x = (acc | (acc >> 1)) & 0x5555555555555555ull;          // bit 2j = map columns 2j, 2j + 1
+                    x = (x | (x >> 1)) & 0x3333333333333333ull;
+                    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+                    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+                    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+                    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+                    bits = (uint32_t)x;
+                } else {
+                    for (int du = 0; du < 2; ++du) {
+                        const uint32_t rb = rowbase[u * 2 + du];
+                        if (rb == 0xFFFFFFFFu) continue;
+                        for (int b = 0; b < 64; ++b) {
+                            const int e = colmap[wv * 64 + b];
+                            if (e < 0) continue;
+                            const int t = s_tab[(rb >> 24) * v.L + (e >> 12)];
+                            if (t < 0) continue;
+                            const int cyb = e & 0xFFF;
+                            const uint32_t wd = v.occ[((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow + (cyb >> 5)];
+                            if ((wd >> (cyb & 31)) & 1u) bits |= 1u << (b >> 1);
+                        }
+                    }
+                }
+                s.occ[u * W + wv] = bits;
+            }
+        } else {
         const int SW = 8;                                       // region words per lane and pass (loads in flight)
         const int WP = (W + 3) & ~3, GT = WP / 4;
         const unsigned slowg = (a.ds != 1 || W > 32 || v.match_stage_slow) ? 0xFFFFFFFFu : s_slowg;
@@ -247,6 +303,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                 }
                 s.occ[u * W + wv] = bits;
             }
+        }
         }
         __syncthreads();                                        // colmap memory is the score table again below
     } else {
