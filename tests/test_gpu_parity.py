@@ -475,3 +475,70 @@ def test_map_update_extreme_beam_counts(eng_mod, B):
         assert_tiles_equal(e, p, oracle_dump(maps[p]), e.dim)
     assert e.counters()["ray_cells_visited"] == sum(m.cells_visited for m in maps)
     e.close()
+
+
+def test_closed_loop_population_equals_oracle(eng_mod):
+    """The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
+    IMU propagation, Robot.map_update with the engine seam doubled (matcher result and proposal samples injected on both
+    sides; one particle takes the NaN-covariance branch once), the map update, and resampling with its deep copies
+    whenever the spread trigger fires.  Ancestors must agree exactly at every step, state within the north-star
+    tolerance, and every particle's map cell for cell at the end."""
+    from thesis_amd.datasets import synthetic
+    P, B, K, T = 6, 181, 30, 9
+    ang = synthetic.beam_angles(B, np.pi)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    truth = np.array([0.2, -0.1, 0.05])
+    e = eng_mod.ParticleEngine(P, max_beams=B, pool_tiles=8 * P)
+    robots = [orc.OracleRobot(0.05) for _ in range(P)]
+    r0 = synthetic.cast_scan(truth, ang, rng)
+    sx, sy = orc.scan_xy(r0, ang)
+    e.set_scan(r0, ang)
+    e.map_update(np.zeros((P, 3)))                               # update_count < 2 branch of main.py:155
+    for rb in robots:
+        rb.map.update((0.0, 0.0, 0.0), sx, sy)
+    resamples = 0
+    for t in range(T):
+        vel = np.array([0.4, 0.1, 0.08]) * (1 + 0.1 * rng.normal(size=3))
+        for _ in range(3):                                       # a few IMU readings per scan
+            e.imu_update("velocity", vel, 300.0)
+            for rb in robots:
+                rb.imu_update("velocity_fr101", vel, 300.0)
+        truth = truth + np.array([0.036, 0.009, 0.0072])
+        r = synthetic.cast_scan(truth, ang, rng)
+        sx, sy = orc.scan_xy(r, ang)
+        e.set_scan(r, ang)
+        poses_in = e.poses()
+        np.testing.assert_allclose(poses_in, [rb.pose() for rb in robots], rtol=1e-9, atol=1e-12)
+        match = np.zeros((P, 13))
+        guesses = np.zeros((P, K, 3))
+        for p in range(P):
+            cov = np.diag([2e-4, 3e-4, 2e-5]) * (1 + 0.3 * p)
+            cov[0, 1] = cov[1, 0] = 5e-5
+            mp = poses_in[p] + rng.normal(0, [0.01, 0.01, 0.003])
+            match[p] = np.concatenate([mp, cov.ravel(), [100.0 + p]])
+            guesses[p] = rng.multivariate_normal(mp, cov, K)
+        if t == 3:
+            match[2, 3:12] = np.nan                              # robot.py:73-78
+        e.scan_update(match_override=match, guesses=guesses)
+        for p, rb in enumerate(robots):
+            rb.map_update(sx, sy, (match[p, :3], match[p, 3:12].reshape(3, 3), match[p, 12]), guesses=guesses[p])
+        w = e.weights()
+        np.testing.assert_allclose(w, [float(rb.weight[-1]) for rb in robots], rtol=1e-9)
+        np.testing.assert_allclose(e.poses(), [rb.pose() for rb in robots], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(e.covs(), [np.asarray(rb.cov, dtype=np.float64) for rb in robots], rtol=1e-5, atol=1e-13)
+        if t in (2, 5, 7):                                       # push the spread past the trigger of main.py:50
+            bump = np.zeros(P); bump[(t * 2) % P] = 260.0; bump[(t + 3) % P] = -40.0
+            e.set_state(weights=w + bump)
+            for p, rb in enumerate(robots):
+                rb.weight[-1] = rb.weight[-1] + bump[p]
+        u = float(rng.random())
+        did, idx = e.resample(u)
+        did_ref, idx_ref = orc.resample_indices([rb.weight[-1] for rb in robots], u)
+        assert did == did_ref and (not did or list(idx) == list(idx_ref)), (t, idx, idx_ref)
+        if did:
+            robots = orc.resample(robots, u)
+            resamples += 1
+    assert resamples >= 3
+    for p, rb in enumerate(robots):
+        assert_tiles_equal(e, p, oracle_dump(rb.map), e.dim)
+    e.close()
