@@ -477,19 +477,24 @@ def test_map_update_extreme_beam_counts(eng_mod, B):
     e.close()
 
 
-def test_closed_loop_population_equals_oracle(eng_mod):
-    """The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
+@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "fan"), (0.1, 180, "window"), (0.05, 721, "window"), (0.025, 181, "fan")])
+def test_closed_loop_population_equals_oracle(eng_mod, monkeypatch, cs, B, kernel):
+    """(Cell sizes of configs C1, C2 and C5, both map-update kernels.)  The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
     IMU propagation, Robot.map_update with the engine seam doubled (matcher result and proposal samples injected on both
     sides; one particle takes the NaN-covariance branch once), the map update, and resampling with its deep copies
     whenever the spread trigger fires.  Ancestors must agree exactly at every step, state within the north-star
     tolerance, and every particle's map cell for cell at the end."""
     from thesis_amd.datasets import synthetic
-    P, B, K, T = 6, 181, 30, 9
-    ang = synthetic.beam_angles(B, np.pi)
+    if kernel == "window":
+        monkeypatch.setenv("RBPF_MAP_KERNEL", "window")
+    else:
+        monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
+    P, K, T = 6, 30, 9
+    ang = synthetic.beam_angles(B, np.pi if B < 400 else 1.5 * np.pi)
     rng = np.random.Generator(np.random.PCG64(2024))
     truth = np.array([0.2, -0.1, 0.05])
-    e = eng_mod.ParticleEngine(P, max_beams=B, pool_tiles=8 * P)
-    robots = [orc.OracleRobot(0.05) for _ in range(P)]
+    e = eng_mod.ParticleEngine(P, max_beams=B, pool_tiles=8 * P, cell_size=cs)
+    robots = [orc.OracleRobot(cs) for _ in range(P)]
     r0 = synthetic.cast_scan(truth, ang, rng)
     sx, sy = orc.scan_xy(r0, ang)
     e.set_scan(r0, ang)
