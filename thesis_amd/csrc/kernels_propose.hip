@@ -89,6 +89,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
     __shared__ int s_sum[KMAX];
     __shared__ int s_tab[49];
+    __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
     __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
     __shared__ int s_bad;
     const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
@@ -119,7 +120,11 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
         }
     }
     const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
-    for (int i = tid; i < LL; i += BLOCK) s_tab[i] = tab[i];
+    for (int i = tid; i < LL; i += BLOCK) {
+        const int t = tab[i];
+        s_tab[i] = t;
+        s_base[i] = t >= 0 ? (unsigned long long)t * (unsigned long long)v.dim * (unsigned long long)v.dim : ~0ull;
+    }
     __syncthreads();
     if (s_bad) {
         if (tid == 0) { v.upd_pose[p] = v.px[p]; v.upd_pose[v.P + p] = v.py[p]; v.upd_pose[2 * v.P + p] = v.pth[p]; }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
                     double gx = (s_c[k0 + k] * x + (-s_s[k0 + k]) * y) + s_g[k0 + k][0];   // lidar.py:123
                     double gy = (s_s[k0 + k] * x + s_c[k0 + k] * y) + s_g[k0 + k][1];
                     int val;
-                    if (lookup_cell_fast(v, s_tab, gx, gy, val)) acc[k] += val;
+                    if (lookup_cell_fast_b(v, s_tab, s_base, gx, gy, val)) acc[k] += val;
                 }
             }
         }
