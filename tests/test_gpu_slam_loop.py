@@ -122,3 +122,34 @@ def test_long_run_fan_kernel_equals_window_kernel(monkeypatch):
         for (_, x), (_, y) in zip(ta, tb):
             assert np.array_equal(x, y)
     a.close(); b.close()
+
+
+def test_map_view_seam_methods():
+    """HybridMapView.get_scan_match / get_scan_adj / is_occ_at: the reference's per-map methods (hybridmap.py:147-261)
+    on one particle's map, through rbpf_match_inputs + rbpf_match_scan."""
+    from thesis_amd.slam import ParticleFilter
+    from thesis_amd.datasets import synthetic
+    from oracle import rbpf_oracle as orc
+    ang = synthetic.beam_angles(1081)
+    rng = np.random.Generator(np.random.PCG64(8))
+    truth = np.array([0.6, -0.2, 0.25])
+    pf = ParticleFilter(2, ang, motion_model="velocity", cell_size=0.05)
+    try:
+        for _ in range(5):
+            pf.engine.set_scan(synthetic.cast_scan(truth, ang, rng), ang)
+            pf.engine.map_update(np.broadcast_to(truth, (2, 3)))
+        view = pf.particles[1]._map
+        # a wall cell of the 16 m room is occupied, the room's interior is not
+        assert view.is_occ_at(8.02, 0.5) and not view.is_occ_at(2.0, 1.0) and not view.is_occ_at(300.0, 0.0)
+        r = synthetic.cast_scan(truth, ang, rng)
+        pf.engine.set_scan(r, ang)
+        guess = truth + [0.12, -0.09, 0.03]
+        pose, cov, score = view.get_scan_match(guess, [0.4, 0.4, np.pi / 6])
+        assert np.all(np.isfinite(cov)) and score > 0
+        assert np.all(np.abs(pose[:2] - truth[:2]) < 0.08) and abs(pose[2] - truth[2]) < 0.01
+        sx, sy = orc.scan_xy(r, ang)
+        gx, gy = orc.transform(sx, sy, tuple(truth))
+        pose, cov, score = view.get_scan_adj(np.stack([sx, sy], 1), np.stack([gx, gy], 1), guess, [0.4, 0.4, np.pi / 6])
+        assert np.all(np.isfinite(cov)) and np.all(np.abs(pose[:2] - truth[:2]) < 0.08) and abs(pose[2] - truth[2]) < 0.01
+    finally:
+        pf.close()

@@ -49,6 +49,37 @@ class HybridMapView:
             ys.append(((j - dim / 2) * self._cell_size + cy) / self._cell_size)
         return (np.concatenate(xs) if xs else np.empty(0)), (np.concatenate(ys) if ys else np.empty(0))
 
+    def is_occ_at(self, x, y) -> bool:                # gridmap.py:255-260 through the tile that holds (x, y)
+        o = self.get_odds_at((x, y))
+        return o is not None and o > self._pf.engine.cfg.occupied_threshold
+
+    def get_scan_match(self, guess, pose_range):      # hybridmap.py:210-261 for the scan last given to the filter
+        """(pose[3], cov[3][3], score) of the engine seam for this particle's map: the point lists of
+        hybridmap.py:213-238, the matcher call with guess 0 and rotation range pi/6 (:244-251), the result offset by
+        the guess (:253-255).  NaN covariance and score 0 mean no valid match (matchScanCustom.m:25-28)."""
+        from .engine import match_scan
+        g = np.asarray([guess.x(), guess.y(), guess.theta()] if hasattr(guess, "theta") else guess, dtype=np.float64)
+        curr, ref = self._pf.engine.match_inputs(self._i, g)
+        pose, cov, score = match_scan(self._pf.engine, curr, ref, [0.0, 0.0, 0.0], int(1.0 / self._cell_size),
+                                      [pose_range[0], pose_range[1], np.pi / 6])
+        return pose + g, cov, score
+
+    def get_scan_adj(self, scan_xy, prev_scan_xy, guess, pose_range):   # hybridmap.py:147-191
+        """The same seam on raw points: `scan_xy` = the current scan in the sensor frame, `prev_scan_xy` = the previous
+        accepted scan in the global frame (main.py:167-168); both translated by -guess.xy, points farther than 11 m
+        dropped (:169-171)."""
+        from .engine import match_scan
+        g = np.asarray([guess.x(), guess.y(), guess.theta()] if hasattr(guess, "theta") else guess, dtype=np.float64)
+        c, s_ = np.cos(g[2]), np.sin(g[2])
+        sc = np.asarray(scan_xy, dtype=np.float64).reshape(-1, 2)
+        curr = np.stack([c * sc[:, 0] - s_ * sc[:, 1], s_ * sc[:, 0] + c * sc[:, 1]], axis=1)      # lidar.py:123 minus guess.xy
+        ref = np.asarray(prev_scan_xy, dtype=np.float64).reshape(-1, 2) - g[:2]
+        curr = curr[np.sqrt((curr ** 2).sum(axis=1)) < 11.0]
+        ref = ref[np.sqrt((ref ** 2).sum(axis=1)) < 11.0]
+        pose, cov, score = match_scan(self._pf.engine, curr, ref, [0.0, 0.0, 0.0], int(1.0 / self._cell_size),
+                                      [pose_range[0], pose_range[1], np.pi / 6])
+        return pose + g, cov, score
+
     def __str__(self):
         return "Hybrid Map: %d maps" % len(self._pf.engine.tiles(self._i))
 
