@@ -112,6 +112,28 @@ void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_
                        static_cast<uint4*>(d_dst), n16);
 }
 
+// two ingests in one launch (the sharded resample hands over two index vectors)
+__global__ void ingest2_kernel(const int32_t* __restrict__ src_a, int32_t* __restrict__ dst_a, const int32_t* __restrict__ src_b,
+                               int32_t* __restrict__ dst_b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { dst_a[i] = src_a[i]; dst_b[i] = src_b[i]; }
+}
+void launch_ingest2(const int32_t* mapped_a, int32_t* d_a, const int32_t* mapped_b, int32_t* d_b, int n, hipStream_t s) {
+    hipLaunchKernelGGL(ingest2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mapped_a, d_a, mapped_b, d_b, n);
+}
+
+// The early resample's read-back written straight into pinned, device-mapped host memory by one kernel:
+// [0] the NaN-branch element of the reduced weight vector (8 bytes), [8] the did flag, [16...] the ancestors.
+__global__ void readback_kernel(unsigned char* __restrict__ dst, const double* __restrict__ nan_elem, const int32_t* __restrict__ did,
+                                const int32_t* __restrict__ idx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<int32_t*>(dst + 16)[i] = idx[i];
+    if (i == 0) { *reinterpret_cast<double*>(dst) = *nan_elem; *reinterpret_cast<int32_t*>(dst + 8) = *did; }
+}
+void launch_readback(void* mapped_dst, const double* d_nan_elem, const int32_t* d_did, const int32_t* d_idx, int n, hipStream_t s) {
+    hipLaunchKernelGGL(readback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<unsigned char*>(mapped_dst), d_nan_elem, d_did, d_idx, n);
+}
+
 void launch_last_scan(const DevView& v, int particle, double* d_out_xy, hipStream_t s) {
     hipLaunchKernelGGL(last_scan_kernel, dim3((v.B + 255) / 256), dim3(256), 0, s, v, particle, d_out_xy);
 }

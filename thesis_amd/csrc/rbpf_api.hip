@@ -712,9 +712,15 @@ int rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global, int
                             h->d_did_early, h->v.err, s);
     HIP_TRY(h, hipGetLastError());
     unsigned char* dst = static_cast<unsigned char*>(h->h_early);
-    HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const double*>(d_global) + n_global, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(dst + 8, h->d_did_early, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(dst + 16, h->d_gidx, (size_t)n_global * 4, hipMemcpyDeviceToHost, s));
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, dst, 0) == hipSuccess && mapped) {      // one kernel writes the landing zone directly
+        launch_readback(mapped, static_cast<const double*>(d_global) + n_global, h->d_did_early, h->d_gidx, n_global, s);
+    } else {
+        (void)hipGetLastError();
+        HIP_TRY(h, hipMemcpyAsync(dst, static_cast<const double*>(d_global) + n_global, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(dst + 8, h->d_did_early, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(dst + 16, h->d_gidx, (size_t)n_global * 4, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(h, hipEventRecord(h->ev_early, s));
     h->early_n = n_global;
     return RBPF_OK;                                      // nothing waited for: what is queued behind it keeps the GPU busy
@@ -760,13 +766,18 @@ int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int3
     int32_t* slot = static_cast<int32_t*>(h->ring_idx.acquire());   // pinned: the caller's arrays are free on return
     memcpy(slot, new_src, (size_t)v.P * 4);
     memcpy(slot + v.P, new_global_id, (size_t)v.P * 4);
-    HIP_TRY(h, hipMemcpyAsync(h->rs.idx, slot, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
+    // both index vectors go over in one kernel from the pinned, device-mapped slot (nothing below reads global_id:
+    // only the weight export does, after this call)
+    void* mapped = nullptr;
+    const bool by_kernel = hipHostGetDevicePointer(&mapped, slot, 0) == hipSuccess && mapped;
+    if (by_kernel) launch_ingest2(static_cast<const int32_t*>(mapped), h->rs.idx, static_cast<const int32_t*>(mapped) + v.P, v.global_id, v.P, h->stream);
+    else { (void)hipGetLastError(); HIP_TRY(h, hipMemcpyAsync(h->rs.idx, slot, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream)); }
     h->prof_begin(2);
     launch_resample_apply_sources(v, h->rs, h->stream);
     h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
-    HIP_TRY(h, hipMemcpyAsync(v.global_id, slot + v.P, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
+    if (!by_kernel) HIP_TRY(h, hipMemcpyAsync(v.global_id, slot + v.P, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
     h->ring_idx.submitted(h->stream);
     return RBPF_OK;                                     // no host synchronisation; device errors surface at the next check
 }

@@ -131,6 +131,8 @@ void launch_weight_samples(const DevView& v, const double* d_guesses, const doub
                            double* d_out_w, hipStream_t s);
 void launch_map_update_fused(const DevView& v, hipStream_t s);   // picks the kernel(s) below
 void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s);   // bytes rounded up to 16
+void launch_ingest2(const int32_t* mapped_a, int32_t* d_a, const int32_t* mapped_b, int32_t* d_b, int n, hipStream_t s);
+void launch_readback(void* mapped_dst, const double* d_nan_elem, const int32_t* d_did, const int32_t* d_idx, int n, hipStream_t s);
 bool map_update_fan_available(const DevView& v);
 void launch_map_update_fan(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
