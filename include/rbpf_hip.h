@@ -213,6 +213,16 @@ int  rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, vo
 int  rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int32_t* new_global_id);
 int  rbpf_unpack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, const void* d_buf,
                            const int32_t* meta_in);
+/* The migration with ONE host wait (thesis_amd/sharding.py): (1) the tile boxes of the departing particles are gathered
+ * into d_raw ([n][rbpf_pack_raw_width()] int32, device) without waiting; the ranks exchange these records while they
+ * are on the device and read their own and the incoming ones back in one copy; (2) records -> the layout rows of
+ * rbpf_unpack_particles and the payload size (host only, no device work); (3) the pack with the records already on
+ * the host (nothing waited for).  Same payload format as rbpf_pack_particles. */
+int32_t rbpf_pack_raw_width(rbpf_handle* h);
+int  rbpf_gather_pack_meta(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_raw);
+int  rbpf_meta_from_raw(rbpf_handle* h, const int32_t* raw, int32_t n, int32_t* meta_out, int64_t* bytes_out);
+int  rbpf_pack_particles_raw(rbpf_handle* h, const int32_t* local_idx, int32_t n, const int32_t* raw, void* d_buf,
+                             int64_t cap_bytes, int64_t* bytes_out);
 
 /* ---- state access (Robot.get_latest_pose/weight, HybridMap readback; main.py:152,170-176) ----- */
 int  rbpf_get_poses(rbpf_handle* h, double* out_p3);

@@ -81,6 +81,10 @@ PROTOTYPES = {
     "rbpf_packed_particle_bytes": (C.c_int64, [_H]),
     "rbpf_pack_particles": (C.c_int, [_H, _I, C.c_int32, C.c_void_p, C.c_int64, _I, C.POINTER(C.c_int64)]),
     "rbpf_unpack_particles": (C.c_int, [_H, _I, C.c_int32, C.c_void_p, _I]),
+    "rbpf_pack_raw_width": (C.c_int32, [_H]),
+    "rbpf_gather_pack_meta": (C.c_int, [_H, _I, C.c_int32, C.c_void_p]),
+    "rbpf_meta_from_raw": (C.c_int, [_H, _I, C.c_int32, _I, C.POINTER(C.c_int64)]),
+    "rbpf_pack_particles_raw": (C.c_int, [_H, _I, C.c_int32, _I, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "rbpf_get_poses": (C.c_int, [_H, _D]),
     "rbpf_get_covs": (C.c_int, [_H, _D]),
     "rbpf_get_weights": (C.c_int, [_H, _D]),

@@ -809,13 +809,47 @@ static int stage_jobs(rbpf_handle* h, const void* src, size_t bytes) {
     return RBPF_OK;
 }
 
+// Layout of n packed particles from their gathered tile boxes (g: per particle and lattice position 5 ints: tile index or
+// -1, x0, x1, y0, y1 - the output of gather_meta_kernel).  Fills the receiver's meta rows (optional) and, for the sender
+// (local_idx given), the pack jobs.  Returns the total payload bytes.  Host only.
+static int64_t layout_packed(const DevView& v, const int32_t* g, int n, const int32_t* local_idx, int32_t* meta_out,
+                             std::vector<PackJobHost>* jobs) {
+    const int LL = v.L * v.L, W = 2 + 6 * LL;
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        int32_t* m = meta_out ? meta_out + (size_t)i * W : nullptr;
+        const int64_t start = off;
+        if (jobs) jobs->push_back({local_idx[i], -1, 0, 0, 0, 0, (long long)off});
+        off += 128;
+        int nt = 0;
+        for (int pos = 0; pos < LL; ++pos) {
+            const int32_t* e = &g[((size_t)i * LL + pos) * 5];
+            int32_t z[6] = {0, 0, 0, 0, 0, 0};
+            int32_t* mm = m ? m + 2 + 6 * pos : z;
+            mm[0] = mm[1] = mm[2] = mm[3] = mm[4] = mm[5] = 0;
+            if (e[0] < 0) continue;
+            ++nt;
+            mm[0] = 1;
+            int x0 = e[1], x1 = e[2], y0 = e[3], y1 = e[4];
+            if (x0 > x1 || y0 > y1) { mm[1] = 0; mm[2] = -1; mm[3] = 0; mm[4] = 0; mm[5] = (int32_t)((off - start) / 16); continue; }   // empty tile
+            int ya = y0 & ~15, yb = std::min((y1 | 15) + 1, v.dim);
+            mm[1] = x0; mm[2] = x1; mm[3] = ya; mm[4] = yb; mm[5] = (int32_t)((off - start) / 16);
+            if (jobs) jobs->push_back({local_idx[i], e[0], x0, x1, ya, yb, (long long)off});
+            int64_t bytes = (int64_t)(x1 - x0 + 1) * (yb - ya) + (int64_t)(x1 - x0 + 1) * v.ow * 4;
+            off += (bytes + 15) & ~(int64_t)15;
+        }
+        if (m) { m[0] = nt; m[1] = (int32_t)((off - start) / 16); }
+    }
+    return off;
+}
+
 int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_buf, int64_t cap_bytes,
                         int32_t* meta_out, int64_t* bytes_out) {
     if (!h || n < 0 || !bytes_out || (n > 0 && (!local_idx || !d_buf || !meta_out))) return RBPF_EINVAL;
     *bytes_out = 0;
     if (n == 0) return RBPF_OK;
     DevView& v = h->v;
-    const int LL = v.L * v.L, W = 2 + 6 * LL;
+    const int LL = v.L * v.L;
     for (int i = 0; i < n; ++i) if (local_idx[i] < 0 || local_idx[i] >= v.P) return fail(h, RBPF_EINVAL, "local index out of range");
     int rc = scratch(h, &h->d_i32, &h->d_i32_cap, (size_t)n * (1 + 5 * LL));
     if (rc) return rc;
@@ -825,30 +859,7 @@ int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, voi
     HIP_TRY(h, hipMemcpyAsync(g.data(), h->d_i32 + n, g.size() * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<PackJobHost> jobs;
-    int64_t off = 0;
-    for (int i = 0; i < n; ++i) {
-        int32_t* m = meta_out + (size_t)i * W;
-        const int64_t start = off;
-        jobs.push_back({local_idx[i], -1, 0, 0, 0, 0, (long long)off});
-        off += 128;
-        int nt = 0;
-        for (int pos = 0; pos < LL; ++pos) {
-            const int32_t* e = &g[((size_t)i * LL + pos) * 5];
-            int32_t* mm = m + 2 + 6 * pos;
-            mm[0] = mm[1] = mm[2] = mm[3] = mm[4] = mm[5] = 0;
-            if (e[0] < 0) continue;
-            ++nt;
-            mm[0] = 1;
-            int x0 = e[1], x1 = e[2], y0 = e[3], y1 = e[4];
-            if (x0 > x1 || y0 > y1) { mm[1] = 0; mm[2] = -1; mm[3] = 0; mm[4] = 0; mm[5] = (int32_t)((off - start) / 16); continue; }   // empty tile
-            int ya = y0 & ~15, yb = std::min((y1 | 15) + 1, v.dim);
-            mm[1] = x0; mm[2] = x1; mm[3] = ya; mm[4] = yb; mm[5] = (int32_t)((off - start) / 16);
-            jobs.push_back({local_idx[i], e[0], x0, x1, ya, yb, (long long)off});
-            int64_t bytes = (int64_t)(x1 - x0 + 1) * (yb - ya) + (int64_t)(x1 - x0 + 1) * v.ow * 4;
-            off += (bytes + 15) & ~(int64_t)15;
-        }
-        m[0] = nt; m[1] = (int32_t)((off - start) / 16);
-    }
+    const int64_t off = layout_packed(v, g.data(), n, local_idx, meta_out, &jobs);
     if (off > cap_bytes) return fail(h, RBPF_ENOMEM, "pack buffer too small");
     rc = stage_jobs(h, jobs.data(), jobs.size() * sizeof(PackJobHost));
     if (rc) return rc;
@@ -856,6 +867,56 @@ int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, voi
     HIP_TRY(h, hipGetLastError());
     *bytes_out = off;
     return RBPF_OK;                                     // the buffer is filled in stream order: send it on the handle's stream
+}
+
+// ---- the same in three steps, with one host wait for a whole migration (thesis_amd/sharding.py) --------------------
+// 1. rbpf_gather_pack_meta: the tile boxes of the departing particles, gathered into a device buffer (nothing waited
+//    for) - the ranks exchange these records while they are still on the device and read their own and the incoming
+//    ones back together;  2. rbpf_meta_from_raw: records -> the layout rows rbpf_unpack_particles takes (host only);
+// 3. rbpf_pack_particles_raw: packs with the records already on the host (nothing waited for).
+int32_t rbpf_pack_raw_width(rbpf_handle* h) { return h ? 5 * h->v.L * h->v.L : -1; }
+
+int rbpf_gather_pack_meta(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_raw) {
+    if (!h || n < 0 || (n > 0 && (!local_idx || !d_raw))) return RBPF_EINVAL;
+    if (n == 0) return RBPF_OK;
+    DevView& v = h->v;
+    if (n > v.P) return fail(h, RBPF_EINVAL, "more departing particles than particles");
+    for (int i = 0; i < n; ++i) if (local_idx[i] < 0 || local_idx[i] >= v.P) return fail(h, RBPF_EINVAL, "local index out of range");
+    int rc = scratch(h, &h->d_i32, &h->d_i32_cap, (size_t)v.P + 4);
+    if (rc) return rc;
+    int32_t* slot = static_cast<int32_t*>(h->ring_idx.acquire());          // pinned: the caller's array is free on return
+    memcpy(slot, local_idx, (size_t)n * 4);
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, slot, 0) == hipSuccess && mapped) launch_ingest(mapped, h->d_i32, (size_t)n * 4, h->stream);
+    else { (void)hipGetLastError(); HIP_TRY(h, hipMemcpyAsync(h->d_i32, slot, (size_t)n * 4, hipMemcpyHostToDevice, h->stream)); }
+    h->ring_idx.submitted(h->stream);
+    launch_gather_meta(v, h->d_i32, n, static_cast<int32_t*>(d_raw), h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return RBPF_OK;
+}
+
+int rbpf_meta_from_raw(rbpf_handle* h, const int32_t* raw, int32_t n, int32_t* meta_out, int64_t* bytes_out) {
+    if (!h || n < 0 || !bytes_out || (n > 0 && (!raw || !meta_out))) return RBPF_EINVAL;
+    *bytes_out = n ? layout_packed(h->v, raw, n, nullptr, meta_out, nullptr) : 0;
+    return RBPF_OK;
+}
+
+int rbpf_pack_particles_raw(rbpf_handle* h, const int32_t* local_idx, int32_t n, const int32_t* raw, void* d_buf,
+                            int64_t cap_bytes, int64_t* bytes_out) {
+    if (!h || n < 0 || !bytes_out || (n > 0 && (!local_idx || !raw || !d_buf))) return RBPF_EINVAL;
+    *bytes_out = 0;
+    if (n == 0) return RBPF_OK;
+    DevView& v = h->v;
+    for (int i = 0; i < n; ++i) if (local_idx[i] < 0 || local_idx[i] >= v.P) return fail(h, RBPF_EINVAL, "local index out of range");
+    std::vector<PackJobHost> jobs;
+    const int64_t off = layout_packed(v, raw, n, local_idx, nullptr, &jobs);
+    if (off > cap_bytes) return fail(h, RBPF_ENOMEM, "pack buffer too small");
+    int rc = stage_jobs(h, jobs.data(), jobs.size() * sizeof(PackJobHost));
+    if (rc) return rc;
+    launch_pack(v, h->d_jobs, (int)jobs.size(), d_buf, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    *bytes_out = off;
+    return RBPF_OK;
 }
 
 // installs n received particles at the given local indices (after rbpf_apply_resample_local); weight <- 1.0 (main.py:77-78)

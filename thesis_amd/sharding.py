@@ -162,6 +162,40 @@ class EngineShard:
             self.e._check(rc)
             return meta, buf[:nbytes.value]
 
+    # the same in three steps with a single host wait (rbpf_gather_pack_meta / rbpf_meta_from_raw / rbpf_pack_particles_raw)
+    @property
+    def raw_width(self):
+        return int(self.e._lib.rbpf_pack_raw_width(self.e._h))
+
+    def gather_pack_meta(self, local_idx):
+        """Tile boxes of the departing particles as a device int32 tensor [n * raw_width]; nothing is waited for."""
+        local_idx = np.ascontiguousarray(local_idx, dtype=np.int32)
+        raw = self.torch.empty(len(local_idx) * self.raw_width, dtype=self.torch.int32, device=self.device)
+        if len(local_idx):
+            self.e._check(self.e._lib.rbpf_gather_pack_meta(self.e._h, local_idx.ctypes.data_as(_I32), len(local_idx), _vp(raw.data_ptr())))
+        return raw
+
+    def meta_from_raw(self, raw, n):
+        """(meta rows for rbpf_unpack_particles, payload bytes per particle) from gathered records on the host."""
+        raw = np.ascontiguousarray(raw, dtype=np.int32)
+        meta = np.zeros((n, self.meta_width), dtype=np.int32)
+        nbytes = _c.c_int64()
+        if n:
+            self.e._check(self.e._lib.rbpf_meta_from_raw(self.e._h, raw.ctypes.data_as(_I32), n, meta.ctypes.data_as(_I32), _c.byref(nbytes)))
+        return meta
+
+    def pack_raw(self, local_idx, raw, nbytes):
+        """Pack with the records already on the host; the buffer is filled in stream order."""
+        local_idx = np.ascontiguousarray(local_idx, dtype=np.int32)
+        raw = np.ascontiguousarray(raw, dtype=np.int32)
+        buf = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+        if len(local_idx):
+            out = _c.c_int64()
+            self.e._check(self.e._lib.rbpf_pack_particles_raw(self.e._h, local_idx.ctypes.data_as(_I32), len(local_idx),
+                                                              raw.ctypes.data_as(_I32), _vp(buf.data_ptr()), int(nbytes), _c.byref(out)))
+            assert out.value == int(nbytes)
+        return buf
+
     def apply_local(self, new_src, new_gid):
         s = np.ascontiguousarray(new_src, dtype=np.int32)
         g = np.ascontiguousarray(new_gid, dtype=np.int32)
@@ -172,8 +206,9 @@ class EngineShard:
         if len(local_idx) == 0:
             return
         meta = np.ascontiguousarray(meta, dtype=np.int32)
-        payload = payload.to(self.device).contiguous()
-        self.torch.cuda.synchronize(self.device)
+        if not payload.is_cuda:                            # host-staged transport: the copy up is synchronous
+            payload = payload.to(self.device)
+        payload = payload.contiguous()                     # on the engine's stream already: stream order is enough
         self.e._check(self.e._lib.rbpf_unpack_particles(self.e._h, local_idx.ctypes.data_as(_I32), len(local_idx),
                                                         _vp(payload.data_ptr()), meta.ctypes.data_as(_I32)))
 
@@ -302,31 +337,53 @@ class ShardedResampler:
             self._book(plan)
             self.stats["resamples"] += 1
             return True, idx
-        # pack what leaves this rank in ONE call, ordered by destination (one gather of the metadata, one kernel);
-        # the per-destination byte counts follow from the metadata rows (16-byte units in column 1)
-        n_out = [len(plan.send[r][d]) for d in range(self.world)]
-        leaving = np.concatenate([np.asarray(plan.send[r][d], dtype=np.int32) for d in range(self.world)]) if sum(n_out) else np.zeros(0, dtype=np.int32)
-        meta_all, pay_all = sh.pack(leaving)
-        ends = np.cumsum(n_out)
-        b_out = [int(meta_all[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_out, ends)]
-        metas, payloads = [meta_all], [pay_all]
-        # the departing particles are packed (stream order): the local part - slot pairing, state permutation, tile
-        # copies of duplicated ancestors - can run now, while the host exchanges the metadata
-        sh.apply_local(plan.new_src[r], plan.new_gid[r])
-        n_in = [len(plan.send[q][r]) for q in range(self.world)]
-        if sum(n_out) + sum(n_in) > 0 or self.world > 1:
-            dev = payloads[0].device
-            meta_send = torch.from_numpy(np.concatenate(metas).reshape(-1)).to(dev)
-            meta_recv = self._all_to_all(meta_send, [n * W for n in n_out], [n * W for n in n_in], torch.int32)
-            meta_in = meta_recv.cpu().numpy().reshape(-1, W)
-            b_in, k = [], 0
-            for q in range(self.world):
-                b_in.append(int(meta_in[k:k + n_in[q], 1].astype(np.int64).sum()) * 16)
-                k += n_in[q]
-            pay_send = torch.cat(payloads) if sum(b_out) else sh.empty_payload(0)
-            pay_recv = self._all_to_all(pay_send, b_out, b_in, torch.uint8)
-        else:
-            meta_in, pay_recv = np.zeros((0, W), dtype=np.int32), sh.empty_payload(0)
+        if hasattr(sh, "gather_pack_meta"):
+            # What leaves this rank, ordered by destination.  One host wait for the whole migration: the tile boxes of the
+            # departing particles are gathered on the device, exchanged between the ranks while still there (the counts per
+            # pair of ranks follow from the plan, which every rank holds), and read back together with the incoming ones.
+            n_out = [len(plan.send[r][d]) for d in range(self.world)]
+            n_in = [len(plan.send[q][r]) for q in range(self.world)]
+            leaving = np.concatenate([np.asarray(plan.send[r][d], dtype=np.int32) for d in range(self.world)]) if sum(n_out) else np.zeros(0, dtype=np.int32)
+            RW = sh.raw_width
+            raw_out = sh.gather_pack_meta(leaving)
+            raw_in = self._all_to_all(raw_out, [n * RW for n in n_out], [n * RW for n in n_in], torch.int32)
+            both = torch.cat([raw_out, raw_in]).cpu().numpy()                    # the wait
+            raw_out_h, raw_in_h = both[:sum(n_out) * RW], both[sum(n_out) * RW:]
+            meta_out, meta_in = sh.meta_from_raw(raw_out_h, sum(n_out)), sh.meta_from_raw(raw_in_h, sum(n_in))
+            ends_o, ends_i = np.cumsum(n_out), np.cumsum(n_in)
+            b_out = [int(meta_out[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_out, ends_o)]
+            b_in = [int(meta_in[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_in, ends_i)]
+            pay_send = sh.pack_raw(leaving, raw_out_h, sum(b_out))
+            # the departing particles are packed (stream order): the local part - slot pairing, state permutation, tile
+            # copies of duplicated ancestors - may now reuse their slots
+            sh.apply_local(plan.new_src[r], plan.new_gid[r])
+            pay_recv = self._all_to_all(pay_send, b_out, b_in, torch.uint8) if (sum(b_out) + sum(b_in) > 0 or self.world > 1) else sh.empty_payload(0)
+        else:                                                                # shards with the one-call pack only (tests)
+            # pack what leaves this rank in ONE call, ordered by destination (one gather of the metadata, one kernel);
+            # the per-destination byte counts follow from the metadata rows (16-byte units in column 1)
+            n_out = [len(plan.send[r][d]) for d in range(self.world)]
+            leaving = np.concatenate([np.asarray(plan.send[r][d], dtype=np.int32) for d in range(self.world)]) if sum(n_out) else np.zeros(0, dtype=np.int32)
+            meta_all, pay_all = sh.pack(leaving)
+            ends = np.cumsum(n_out)
+            b_out = [int(meta_all[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_out, ends)]
+            metas, payloads = [meta_all], [pay_all]
+            # the departing particles are packed (stream order): the local part - slot pairing, state permutation, tile
+            # copies of duplicated ancestors - can run now, while the host exchanges the metadata
+            sh.apply_local(plan.new_src[r], plan.new_gid[r])
+            n_in = [len(plan.send[q][r]) for q in range(self.world)]
+            if sum(n_out) + sum(n_in) > 0 or self.world > 1:
+                dev = payloads[0].device
+                meta_send = torch.from_numpy(np.concatenate(metas).reshape(-1)).to(dev)
+                meta_recv = self._all_to_all(meta_send, [n * W for n in n_out], [n * W for n in n_in], torch.int32)
+                meta_in = meta_recv.cpu().numpy().reshape(-1, W)
+                b_in, k = [], 0
+                for q in range(self.world):
+                    b_in.append(int(meta_in[k:k + n_in[q], 1].astype(np.int64).sum()) * 16)
+                    k += n_in[q]
+                pay_send = torch.cat(payloads) if sum(b_out) else sh.empty_payload(0)
+                pay_recv = self._all_to_all(pay_send, b_out, b_in, torch.uint8)
+            else:
+                meta_in, pay_recv = np.zeros((0, W), dtype=np.int32), sh.empty_payload(0)
         arrivals = np.nonzero(plan.new_src[r] < 0)[0].astype(np.int32)
         sh.unpack(arrivals, meta_in, pay_recv)
         self._book(plan)
