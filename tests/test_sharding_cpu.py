@@ -110,7 +110,31 @@ class NumpyShard:
         return self.states[i][:3]
 
 
-def _worker(rank, world, p_local, port, rounds, out_q):
+class NumpyShardRaw(NumpyShard):
+    """The same double with the three-step migration protocol of EngineShard (records exchanged before the pack:
+    rbpf_gather_pack_meta / rbpf_meta_from_raw / rbpf_pack_particles_raw), which ShardedResampler prefers."""
+    raw_width = 5
+
+    def gather_pack_meta(self, local_idx):
+        rec = np.array([[int(li) + 1000, 176 // 16, 7, 8, 9] for li in local_idx], dtype=np.int32).reshape(-1)
+        return self.torch.from_numpy(rec) if len(rec) else self.torch.empty(0, dtype=self.torch.int32)
+
+    def meta_from_raw(self, raw, n):
+        raw = np.asarray(raw, dtype=np.int32).reshape(n, 5)
+        assert n == 0 or (np.all(raw[:, 2:] == [7, 8, 9]) and np.all(raw[:, 0] >= 1000))
+        meta = np.zeros((n, 4), dtype=np.int32)
+        meta[:, 0] = 1
+        meta[:, 1] = raw[:, 1]
+        return meta
+
+    def pack_raw(self, local_idx, raw, nbytes):
+        assert [int(x) - 1000 for x in np.asarray(raw).reshape(-1, 5)[:, 0]] == [int(x) for x in local_idx]
+        _, pay = self.pack(local_idx)
+        assert pay.numel() == nbytes
+        return pay
+
+
+def _worker(rank, world, p_local, port, rounds, out_q, flavour="pack"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -120,7 +144,7 @@ def _worker(rank, world, p_local, port, rounds, out_q):
     rng = np.random.Generator(np.random.PCG64(42))
     states = rng.normal(size=(n, 13)); tags = rng.integers(0, 255, size=(n, 48)).astype(np.uint8)
     sl = slice(rank * p_local, (rank + 1) * p_local)
-    shard = NumpyShard(list(states[sl]), list(tags[sl]))
+    shard = (NumpyShardRaw if flavour == "raw" else NumpyShard)(list(states[sl]), list(tags[sl]))
     sr = ShardedResampler(rank, world, p_local)
     sr.attach(shard)
     history = []
@@ -136,14 +160,14 @@ def _worker(rank, world, p_local, port, rounds, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,p_local", [(2, 8), (2, 33), (4, 12), (8, 5)])
-def test_sharded_resample_gloo_matches_single_process(world, p_local):
+@pytest.mark.parametrize("world,p_local,flavour", [(2, 8, "pack"), (2, 33, "raw"), (4, 12, "raw"), (8, 5, "raw"), (8, 5, "pack")])
+def test_sharded_resample_gloo_matches_single_process(world, p_local, flavour):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     rounds = 3
-    procs = [ctx.Process(target=_worker, args=(r, world, p_local, port, rounds, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, p_local, port, rounds, q, flavour)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
