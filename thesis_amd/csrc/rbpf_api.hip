@@ -545,9 +545,10 @@ int rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_
     launch_propose_weight(v, h->d_match, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
     h->prof_end(1);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev_weights, h->stream));
-    h->ev_weights_valid = true;
-    h->scan_begun = true;
+    // the event orders an early weight export on ANOTHER stream behind the weighting; recorded only once such a caller exists
+    h->ev_weights_valid = false;
+    if (h->record_ev_weights) { HIP_TRY(h, hipEventRecord(h->ev_weights, h->stream)); h->ev_weights_valid = true; }
+    h->scan_begun = true; h->begin_seen = true;
     return RBPF_OK;
 }
 
@@ -686,9 +687,15 @@ int rbpf_export_weights(rbpf_handle* h, void* d_global, int32_t n_global) {
 
 int rbpf_export_weights_early(rbpf_handle* h, void* d_global, int32_t n_global, void* aux_stream) {
     if (!h || !d_global || n_global < h->v.P) return RBPF_EINVAL;
-    if (!h->ev_weights_valid) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
+    if (!h->begin_seen) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
     hipStream_t s = static_cast<hipStream_t>(aux_stream);
-    HIP_TRY(h, hipStreamWaitEvent(s, h->ev_weights, 0));
+    if (s != h->stream) {                                 // same stream: stream order is the ordering
+        if (!h->ev_weights_valid) {                       // first such call: order behind everything queued so far, record in time from now on
+            HIP_TRY(h, hipEventRecord(h->ev_weights, h->stream));
+            h->ev_weights_valid = true; h->record_ev_weights = true;
+        }
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_weights, 0));
+    }
     launch_export_weights(h->v, static_cast<double*>(d_global), n_global, h->d_bad, s);
     HIP_TRY(h, hipGetLastError());
     return RBPF_OK;

@@ -96,7 +96,7 @@ struct rbpf_handle {
         void submitted(hipStream_t s) { (void)hipEventRecord(ev[next], s); used[next] = true; next = (next + 1) % N; }
     };
     PinnedRing ring_scan, ring_last, ring_idx;
-    hipEvent_t ev_weights = nullptr; bool ev_weights_valid = false;   // recorded after the weighting kernel of rbpf_scan_update_begin
+    hipEvent_t ev_weights = nullptr; bool ev_weights_valid = false, record_ev_weights = false, begin_seen = false;   // recorded after the weighting kernel of rbpf_scan_update_begin
     int32_t* d_did_early = nullptr; bool scan_begun = false;
     void* h_jobs = nullptr; size_t h_jobs_bytes = 0; hipEvent_t ev_jobs = nullptr; bool h_jobs_used = false;   // pinned job-list staging
     hipEvent_t ev_early = nullptr; void* h_early = nullptr; size_t h_early_bytes = 0; int early_n = 0;   // early resample read-back
