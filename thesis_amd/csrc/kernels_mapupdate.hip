@@ -98,10 +98,9 @@ __device__ __forceinline__ void walk_flagged(const MuLds& s, int cc, uint32_t hv
 }
 
 
-// only != nullptr: process just the particles the whole-fan kernel gave back (only[p] != 0)
-__global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v, const int32_t* __restrict__ only) {   // 2 workgroups per CU
+// one particle's map update by one workgroup; `only`: this launch follows the whole-fan kernel and takes what it gave back
+__device__ __forceinline__ void map_update_particle(const DevView& v, bool only) {
     extern __shared__ __align__(16) unsigned char smem[];
-    if (only && !only[blockIdx.x]) return;
     const int NB = mu_nb(v.B);
     MuLds s;
     s.cnt = reinterpret_cast<uint32_t*>(smem);
@@ -705,7 +704,19 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v, cons
     }
 }
 
-void launch_map_update_fused(const DevView& v, hipStream_t s) {
+// only != nullptr: process just the particles the whole-fan kernel gave back (only[p] != 0).  bad != nullptr: particles
+// on the NaN-covariance branch (robot.py:73-78) get their weight increment here, after their map is updated (by this
+// workgroup or, earlier, by the whole-fan kernel): one launch less per step.
+__global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v, const int32_t* __restrict__ only,
+                                                                 const uint8_t* __restrict__ bad) {   // 2 workgroups per CU
+    if (!only || only[blockIdx.x]) map_update_particle(v, only != nullptr);
+    if (bad && bad[blockIdx.x]) {
+        __syncthreads();
+        nan_branch_weight(v, blockIdx.x, threadIdx.x, MU_BLOCK);
+    }
+}
+
+void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s) {
     size_t lds = raycast_lds_bytes(v.B, v.reach);
     static size_t lds_attr = 0;
     if (lds > lds_attr) {   // more than the default 64 KiB of dynamic LDS
@@ -715,7 +726,7 @@ void launch_map_update_fused(const DevView& v, hipStream_t s) {
     }
     const bool fan = v.mu_mode == 0 && map_update_fan_available(v);
     if (fan) launch_map_update_fan(v, s);
-    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr);
+    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, d_bad);
 }
 
 }  // namespace rbpf

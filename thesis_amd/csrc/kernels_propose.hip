@@ -219,33 +219,8 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
 // robot.py:75-77 for particles on the NaN branch: weight += (1 + sum log-odds at the latest pose) * 1,
 // evaluated on the map AFTER its update.
 __global__ __launch_bounds__(BLOCK) void bad_weight_kernel(DevView v, const uint8_t* __restrict__ bad) {
-    __shared__ int s_sum;
-    __shared__ int s_tab[49];
-    const int p = blockIdx.x, tid = threadIdx.x;
-    if (!bad[p]) return;
-    const int LL = v.L * v.L;
-    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
-    for (int i = tid; i < LL; i += BLOCK) s_tab[i] = tab[i];
-    if (tid == 0) s_sum = 0;
-    __syncthreads();
-    double sn, cs;
-    sincos(v.pth[p], &sn, &cs);
-    const double tx = v.px[p], ty = v.py[p];
-    int acc = 0;
-    for (int b = tid; b < v.B; b += BLOCK) {
-        if (!(v.bflags[b] & BF_WEIGHT)) continue;
-        const double x = v.bx[b], y = v.by[b];
-        double gx = (cs * x + (-sn) * y) + tx, gy = (sn * x + cs * y) + ty;
-        int val;
-        if (lookup_cell_fast(v, s_tab, gx, gy, val)) acc += val;
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((tid & 63) == 0) atomicAdd(&s_sum, acc);
-    __syncthreads();
-    if (tid == 0) {
-        double obs = v.inv_quantum > 0 ? (v.inv_quantum + (double)s_sum) / v.inv_quantum : 1.0 + (double)s_sum * v.quantum;
-        v.weight[p] = obs * 1.0 + v.weight[p];
-    }
+    if (!bad[blockIdx.x]) return;
+    nan_branch_weight(v, blockIdx.x, threadIdx.x, BLOCK);
 }
 
 void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,

@@ -458,10 +458,10 @@ int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs
 }
 
 // ---- a5 test entry --------------------------------------------------------------------------------------
-static int run_map_update(rbpf_handle* h) {
+static int run_map_update(rbpf_handle* h, const uint8_t* d_bad = nullptr) {
     DevView& v = h->v;
     h->prof_begin(0);
-    launch_map_update_fused(v, h->stream);
+    launch_map_update_fused(v, d_bad, h->stream);
     h->prof_end(0);
     HIP_TRY(h, hipGetLastError());
     h->scan_updates++;
@@ -557,12 +557,9 @@ int rbpf_scan_update_end(rbpf_handle* h) {
     if (!h) return RBPF_EINVAL;
     if (!h->scan_begun) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
     h->scan_begun = false;
-    DevView& v = h->v;
-    int rc = run_map_update(h);                 // HybridMap.update at the new mean pose (robot.py:115)
-    if (rc) return rc;
-    launch_bad_weight(v, h->d_bad, h->stream);  // robot.py:73-78 fallback, after the map update
-    HIP_TRY(h, hipGetLastError());
-    return RBPF_OK;
+    // HybridMap.update at the new mean pose (robot.py:115), then - in the same launch - the robot.py:73-78 weight
+    // increment of the particles on the NaN-covariance branch, on their updated maps
+    return run_map_update(h, h->d_bad);
 }
 
 // matchScanCustom(curr, ref, guess, cells_per_m, pose_range) -> pose, cov, score  (hybridmap.py:244-251)

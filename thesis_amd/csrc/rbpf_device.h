@@ -67,6 +67,36 @@ __device__ __forceinline__ bool lookup_cell_fast_b(const DevView& v, const int32
     return true;
 }
 
+// robot.py:75-77 for a particle on the NaN-covariance branch: weight += (1 + sum of the log-odds under the scan at the
+// latest pose) * 1, evaluated on the map AFTER its update.  Whole workgroup (contains barriers).
+__device__ inline void nan_branch_weight(const DevView& v, int p, int tid, int nthreads) {
+    __shared__ int s_sum_nb;
+    __shared__ int s_tab_nb[49];
+    const int LL = v.L * v.L;
+    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+    for (int i = tid; i < LL; i += nthreads) s_tab_nb[i] = tab[i];
+    if (tid == 0) s_sum_nb = 0;
+    __syncthreads();
+    double sn, cs;
+    sincos(v.pth[p], &sn, &cs);
+    const double tx = v.px[p], ty = v.py[p];
+    int acc = 0;
+    for (int b = tid; b < v.B; b += nthreads) {
+        if (!(v.bflags[b] & BF_WEIGHT)) continue;                        // robot.py:130
+        const double x = v.bx[b], y = v.by[b];
+        double gx = (cs * x + (-sn) * y) + tx, gy = (sn * x + cs * y) + ty;
+        int val;
+        if (lookup_cell_fast(v, s_tab_nb, gx, gy, val)) acc += val;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) atomicAdd(&s_sum_nb, acc);
+    __syncthreads();
+    if (tid == 0) {
+        double obs = v.inv_quantum > 0 ? (v.inv_quantum + (double)s_sum_nb) / v.inv_quantum : 1.0 + (double)s_sum_nb * v.quantum;
+        v.weight[p] = obs * 1.0 + v.weight[p];
+    }
+}
+
 // ---- LUT helpers ------------------------------------------------------------------------------
 __device__ __forceinline__ bool lut_valid_g(const DevView& v, int g) {
     return g >= v.g_min && g < v.g_min + v.n_lut;

@@ -129,7 +129,7 @@ namespace rbpf {
 // kernel launchers (one translation unit per kernel family)
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
-void launch_map_update_fused(const DevView& v, hipStream_t s);   // picks the kernel(s) below
+void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s);   // picks the kernel(s) below; d_bad: NaN-branch weight increments after the update (or nullptr)
 void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s);   // bytes rounded up to 16
 void launch_ingest2(const int32_t* mapped_a, int32_t* d_a, const int32_t* mapped_b, int32_t* d_b, int n, hipStream_t s);
 void launch_readback(void* mapped_dst, const double* d_nan_elem, const int32_t* d_did, const int32_t* d_idx, int n, hipStream_t s);
