@@ -113,6 +113,9 @@ int  rbpf_set_stream(rbpf_handle* h, void* hip_stream); /* e.g. torch's current 
 int  rbpf_synchronize(rbpf_handle* h);
 int  rbpf_get_counters(rbpf_handle* h, rbpf_counters* out);
 int  rbpf_set_profiling(rbpf_handle* h, int on);     /* per-kernel HIP events; resets the rings */
+/* the same for a subset of the kernel families (bit k = family k of rbpf_get_kernel_ms): every record costs a few
+ * microseconds of stream time, a benchmark brackets only what it needs inside its timed region */
+int  rbpf_set_profiling_families(rbpf_handle* h, uint32_t mask);
 /* durations (ms) of the launches recorded since rbpf_set_profiling, HIP events on the handle's stream;
  * which: 0 ray-cast map-update kernel, 1 proposal/weighting kernel, 2 resample kernels, 3 scan-match grid stage,
  * 4 scan-match NDT stage.  Synchronises the stream. */

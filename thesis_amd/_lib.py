@@ -56,6 +56,7 @@ PROTOTYPES = {
     "rbpf_synchronize": (C.c_int, [_H]),
     "rbpf_get_counters": (C.c_int, [_H, C.POINTER(RbpfCounters)]),
     "rbpf_set_profiling": (C.c_int, [_H, C.c_int]),
+    "rbpf_set_profiling_families": (C.c_int, [_H, C.c_uint32]),
     "rbpf_get_kernel_ms": (C.c_int, [_H, C.c_int32, _D, C.c_int32, _I]),
     "rbpf_set_scan": (C.c_int, [_H, _D, _D, C.c_int32]),
     "rbpf_imu_update": (C.c_int, [_H, C.c_int32, _D, C.c_double]),

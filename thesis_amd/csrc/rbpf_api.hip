@@ -321,9 +321,15 @@ int rbpf_synchronize(rbpf_handle* h) {
     return check_device_error(h);
 }
 
+int rbpf_set_profiling_families(rbpf_handle* h, uint32_t mask) {
+    if (!h) return RBPF_EINVAL;
+    return rbpf_set_profiling(h, mask ? (int)(0x100u | (mask & 0x1Fu)) : 0);
+}
+
 int rbpf_set_profiling(rbpf_handle* h, int on) {
     if (!h) return RBPF_EINVAL;
     h->profiling = on != 0;
+    h->prof_mask = !on ? 0u : (on & 0x100) ? ((unsigned)on & 0x1Fu) : 0x1Fu;
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) h->ring_n[k] = 0;
     h->last_end = nullptr;
     HIP_TRY(h, hipMemsetAsync(h->v.stats, 0, ST_COUNT * sizeof(unsigned long long), h->stream));   // counters restart

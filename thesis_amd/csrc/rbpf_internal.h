@@ -82,6 +82,7 @@ struct rbpf_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
+    unsigned prof_mask = 0;                     // kernel families whose launches are bracketed by timing events (bit k = family k)
     bool have_scan = false;
     std::string err;
     std::vector<uint32_t> h_lut;
@@ -116,10 +117,10 @@ struct rbpf_handle {
     int ring_n[N_KERN] = {0, 0, 0, 0, 0};
     std::vector<hipEvent_t> begin_used[N_KERN];     // the event that marks a launch's start: its own, or the previous family's end
     hipEvent_t last_end = nullptr;
-    void prof_begin(int k) { if (!profiling) return; hipEvent_t e = ring[k][0][ring_n[k] % RING]; (void)hipEventRecord(e, stream); begin_used[k][ring_n[k] % RING] = e; }
+    void prof_begin(int k) { if (!((prof_mask >> k) & 1u)) return; hipEvent_t e = ring[k][0][ring_n[k] % RING]; (void)hipEventRecord(e, stream); begin_used[k][ring_n[k] % RING] = e; }
     // the previous timed family ended right before this one starts (nothing enqueued in between): one record serves both
-    void prof_begin_chained(int k) { if (!profiling) return; if (!last_end) { prof_begin(k); return; } begin_used[k][ring_n[k] % RING] = last_end; }
-    void prof_end(int k) { if (!profiling) return; last_end = ring[k][1][ring_n[k] % RING]; (void)hipEventRecord(last_end, stream); ring_n[k]++; }
+    void prof_begin_chained(int k) { if (!((prof_mask >> k) & 1u)) return; if (!last_end) { prof_begin(k); return; } begin_used[k][ring_n[k] % RING] = last_end; }
+    void prof_end(int k) { if (!((prof_mask >> k) & 1u)) return; last_end = ring[k][1][ring_n[k] % RING]; (void)hipEventRecord(last_end, stream); ring_n[k]++; }
     rbpf::ResampleBuffers rs;
     rbpf_counters counters;
     unsigned long long scan_updates = 0;

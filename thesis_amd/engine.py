@@ -90,8 +90,16 @@ class ParticleEngine:
     def synchronize(self):
         self._check(self._lib.rbpf_synchronize(self._h))
 
-    def set_profiling(self, on: bool):
-        self._check(self._lib.rbpf_set_profiling(self._h, int(on)))
+    def set_profiling(self, on):
+        """True / False: timing events around every kernel family / none; a list of family names (KERNELS): only those
+        (each record costs a few microseconds of stream time).  Restarts the counters."""
+        if isinstance(on, (list, tuple, set)):
+            mask = 0
+            for k in on:
+                mask |= 1 << self.KERNELS[k]
+            self._check(self._lib.rbpf_set_profiling_families(self._h, mask))
+        else:
+            self._check(self._lib.rbpf_set_profiling(self._h, int(bool(on))))
 
     KERNELS = {"raycast": 0, "weight": 1, "resample": 2, "match": 3, "ndt": 4}
 
