@@ -313,6 +313,7 @@ def main():
                 "ndt": {"enabled": bool(args.ndt), "runs_per_step": c["ndt_runs"] / n_upd,
                         "evaluations_per_run": c["ndt_evaluations"] / max(1, c["ndt_runs"]),
                         "accepted_fraction": c["ndt_accepted"] / max(1, c["ndt_runs"])},
+                "match_shared_per_step": c["match_shared"] / n_upd,       # exact duplicates that took their representative's match
                 "window_fallback_particles_per_step": c["window_fallbacks"] / n_upd,
                 "unique_cells_written_per_particle": W_per_particle,
                 "ray_cells_per_particle": cells_per_particle}

@@ -101,6 +101,8 @@ typedef struct rbpf_counters {
     uint64_t ndt_runs;            /* matches that entered the NDT stage                           */
     uint64_t ndt_evaluations;     /* NDT score/gradient/Hessian evaluations, summed over runs     */
     uint64_t ndt_accepted;        /* runs whose pose replaced the grid pose (matchScanCustom.m:39-41) */
+    uint64_t match_shared;        /* particles that took the match result of an exact duplicate (a copy made by the
+                                     last resample: same pose, covariance and map) instead of repeating the search */
 } rbpf_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -153,3 +153,32 @@ def test_map_view_seam_methods():
         assert np.all(np.isfinite(cov)) and np.all(np.abs(pose[:2] - truth[:2]) < 0.08) and abs(pose[2] - truth[2]) < 0.01
     finally:
         pf.close()
+
+
+def _run_loop(steps, P=48, seed=5):
+    from bench import Runner, PERIOD_S
+    from thesis_amd.datasets import synthetic
+    log = synthetic.make_log(steps + 3, 1081, period=PERIOD_S)
+    r = Runner(P, 1081, 0.05, log)
+    for _ in range(steps):
+        r.step()
+    out = (r.e.poses(), r.e.covs(), r.e.weights(), [dict(r.e.tiles(p)) for p in (0, P // 2, P - 1)], r.e.counters())
+    r.e.close()
+    return out
+
+
+def test_sharing_the_match_of_exact_duplicates_changes_nothing(monkeypatch):
+    """After a resample the copies of one ancestor have the same pose, covariance and map until the next proposal
+    draws their samples, so their scan matches are identical: the matcher runs once per group and the proposal reads
+    the representative's result.  RBPF_MATCH_DEDUP=0 runs every particle; both must give the same bits everywhere."""
+    monkeypatch.delenv("RBPF_MATCH_DEDUP", raising=False)
+    a = _run_loop(25)
+    monkeypatch.setenv("RBPF_MATCH_DEDUP", "0")
+    b = _run_loop(25)
+    assert a[4]["match_shared"] > 0 and b[4]["match_shared"] == 0
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    for ta, tb in zip(a[3], b[3]):
+        assert set(ta) == set(tb)
+        for c in ta:
+            assert np.array_equal(ta[c], tb[c])

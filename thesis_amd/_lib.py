@@ -36,7 +36,7 @@ class RbpfCounters(C.Structure):
         ("bytes_copied", C.c_uint64), ("ms_raycast", C.c_double), ("ms_weight", C.c_double),
         ("ms_match", C.c_double), ("ms_resample", C.c_double), ("slow_cells", C.c_uint64),
         ("reserved", C.c_uint64 * 7), ("window_fallbacks", C.c_uint64), ("ndt_runs", C.c_uint64), ("ndt_evaluations", C.c_uint64),
-        ("ndt_accepted", C.c_uint64),
+        ("ndt_accepted", C.c_uint64), ("match_shared", C.c_uint64),
     ]
 
 

@@ -62,6 +62,7 @@ struct MatchArgs {
     int ndt;                    // 0 off; 1 matchScanCustom.m:38-44 acceptance; 2 take every valid NDT pose (diagnostic)
     int ndt_nc;                 // NDT cell edge in matcher cells (0.1 m, matchScanCustom.m:37); < 2: no cell can hold 3 points
     int ndt_max_iter;           // matchScanCustom.m:36
+    const int32_t* dup_of;      // particles whose entry is not their own index are exact duplicates of that particle: skipped
     uint32_t* ndt_occ;          // [particles][N][N/32] the staged occupancy field, handed to the NDT kernel
     double* ndt_aux;            // [particles][5] grid optimum (cells, cells, rad), its full score, ok flag
 };
@@ -120,6 +121,9 @@ __device__ inline void match_frame(const DevView& v, const MatchArgs& a, int p, 
 __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, W = N >> 5, tid = threadIdx.x, p = blockIdx.x;
+    // An exact duplicate (a copy made by the last resample: same pose, covariance and map) would repeat its
+    // representative's search bit for bit; the proposal kernel reads the representative's row instead.
+    if (a.dup_of && a.dup_of[p] != p) { if (tid == 0) atomicAdd(&v.stats[ST_MATCH_SHARED], 1ull); return; }
     MatchLds s;
     s.occ = reinterpret_cast<uint32_t*>(smem);
     s.dil = s.occ + (size_t)N * W;
@@ -751,6 +755,7 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
 #ifdef RBPF_STAMPS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
 #endif
+    if (a.dup_of && a.dup_of[p] != p) return;                  // exact duplicate of another particle (see match_kernel)
     const double* aux = a.ndt_aux + (size_t)p * 5;
     if (aux[4] == 0.0 || a.n_sel <= 0) return;                  // the grid stage failed: matchScanCustom.m:25-28, uniform
     if (tid == 0) { match_frame(v, a, p, s_g, s_rng, s_org); s_ok = 0; }
@@ -956,6 +961,7 @@ bool launch_match_particles(const DevView& v, int mode, const double* d_ref, int
     a.sel_x = mode ? v.asel_x : v.msel_x; a.sel_y = mode ? v.asel_y : v.msel_y; a.n_sel = mode ? v.n_asel : v.n_msel;
     a.n_coarse_rot = ncr; a.cap_sel = cap_sel;
     a.ndt = v.ndt_refine; a.ndt_nc = ndt_cells(mcs); a.ndt_max_iter = 500;
+    a.dup_of = v.dups_valid ? v.dup_of : nullptr;
     const bool ndt = a.ndt && a.ndt_nc >= 2 && v.ndt_occ;
     if (ndt) { a.ndt_occ = v.ndt_occ; a.ndt_aux = v.ndt_aux; }
     if (stage == 1) launch_match(v, a, v.P, lds, s);

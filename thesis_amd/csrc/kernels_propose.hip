@@ -77,6 +77,7 @@ __device__ void eig3_sym(const double A[9], double w[3], double V[3][3]) {
 
 struct ProposeArgs {
     const double* match;        // [P][13] scan_pose(3), scan_cov(9), score
+    const int32_t* match_of;    // the matcher ran once per group of exact duplicates: row of particle p = match_of[p] (or nullptr)
     const double* guesses;      // [P][K][3] explicit samples, or nullptr
     uint8_t* bad;               // [P] 1 = NaN covariance (robot.py:73)
     uint64_t seed; uint32_t stream;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     __shared__ int s_bad;
     const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
     const int LL = v.L * v.L;
-    const double* m = a.match + (size_t)p * 13;
+    const double* m = a.match + (size_t)(a.match_of ? a.match_of[p] : p) * 13;
 
     if (tid == 0) {
         bool bad = false;
@@ -223,9 +224,9 @@ __global__ __launch_bounds__(BLOCK) void bad_weight_kernel(DevView v, const uint
     nan_branch_weight(v, blockIdx.x, threadIdx.x, BLOCK);
 }
 
-void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,
+void launch_propose_weight(const DevView& v, const double* d_match, const int32_t* d_match_of, const double* d_guesses, uint8_t* d_bad,
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s) {
-    ProposeArgs a{d_match, d_guesses, d_bad, seed, stream, d_dbg_w};
+    ProposeArgs a{d_match, d_match_of, d_guesses, d_bad, seed, stream, d_dbg_w};
     hipLaunchKernelGGL(propose_weight_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, a);
 }
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s) {

@@ -224,9 +224,12 @@ struct GatherArgs {
     const int32_t* idx; const int32_t* did;
     const double *px, *py, *pth, *cov, *w;
     double *px2, *py2, *pth2, *cov2, *w2;
+    const int32_t* T; int32_t* dup_of;  // dup_of[j] = first new particle with j's ancestor: the copies of one ancestor are
+                                        // exact duplicates (state and map) until the next proposal draws their samples
 };
 __device__ __forceinline__ void resample_gather_one(const GatherArgs& a, int j) {
     const int i = a.idx[j];
+    if (a.dup_of) a.dup_of[j] = (i >= 0 && *a.did) ? (i > 0 ? a.T[i - 1] : 0) : j;
     if (i < 0) return;                 // arrives from another rank: filled by the unpack kernel
     a.px2[j] = a.px[i]; a.py2[j] = a.py[i]; a.pth2[j] = a.pth[i];
 #pragma unroll
@@ -571,7 +574,7 @@ void launch_resample_local(const DevView& v, const ResampleBuffers& b, const dou
     }
     FusedArgs f{RS_PLAN | RS_EXPAND | RS_PAIR | RS_GATHER, ResampleArgs{v.P, d_w, u, spread, b.T, b.did, v.err}, b.idx,
                 PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
-                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2}};
+                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of}};
     hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
@@ -587,7 +590,7 @@ void launch_resample_apply_sources(const DevView& v, const ResampleBuffers& b, h
     }
     FusedArgs f{RS_SRC2T | RS_PAIR | RS_GATHER, ResampleArgs{v.P, nullptr, 0.0, 0.0, b.T, b.did, v.err}, b.idx,
                 PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
-                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2}};
+                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of}};
     hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
@@ -598,7 +601,7 @@ void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream
     PairArgs pa{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err};
     hipLaunchKernelGGL(resample_pair_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, pa);
     GatherArgs ga{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight,
-                  b.px2, b.py2, b.pth2, b.cov2, b.w2};
+                  b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of};
     hipLaunchKernelGGL(resample_gather_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, ga);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);

@@ -234,7 +234,10 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
             v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
             v.ndt_refine = h->cfg.ndt_refine;
+            const char* dd = getenv("RBPF_MATCH_DEDUP");     // "0": every particle runs the matcher, duplicates included (tests)
+            h->dedup_enabled = !(dd && std::string(dd) == "0");
         }
+        ALLOC(h, v.dup_of, P); v.dups_valid = 0;
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
         if (raycast_lds_bytes(c.max_beams, v.reach) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
         match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
@@ -368,6 +371,7 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.tiles_in_use = (uint64_t)(h->v.pool_tiles - top);
     c.window_fallbacks = st[ST_WINDOW_FALLBACKS];
     c.ndt_runs = st[ST_NDT_RUNS]; c.ndt_evaluations = st[ST_NDT_EVALS]; c.ndt_accepted = st[ST_NDT_ACCEPTED];
+    c.match_shared = st[ST_MATCH_SHARED];
     for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];
     // diagnostic slot: four 16-bit tallies of whole-fan fallback reasons, or the eighth phase stamp of a -DRBPF_STAMPS build
     c.cells_gathered = st[15] ? st[15] : st[ST_FALLBACK_REASONS];
@@ -476,6 +480,7 @@ static int run_map_update(rbpf_handle* h, const uint8_t* d_bad = nullptr) {
 
 int rbpf_map_update(rbpf_handle* h, const double* poses) {
     if (!h) return RBPF_EINVAL;
+    h->v.dups_valid = 0;
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     DevView& v = h->v;
     const size_t P = v.P;
@@ -548,7 +553,11 @@ int rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_
         d_g = h->d_guess_full;
     }
     if (!match_override && !guesses) h->prof_begin_chained(1); else h->prof_begin(1);     // right after the matcher's last kernel
-    launch_propose_weight(v, h->d_match, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
+    // the matcher ran once per group of exact duplicates (copies made by the last resample, untouched since): every
+    // member reads its representative's row; the proposal below is what makes the copies differ, so the groups end here
+    const int32_t* match_of = (!match_override && v.dups_valid) ? v.dup_of : nullptr;
+    launch_propose_weight(v, h->d_match, match_of, d_g, h->d_bad, h->cfg.seed, (uint32_t)h->scan_updates, nullptr, h->stream);
+    v.dups_valid = 0;
     h->prof_end(1);
     HIP_TRY(h, hipGetLastError());
     // the event orders an early weight export on ANOTHER stream behind the weighting; recorded only once such a caller exists
@@ -667,6 +676,7 @@ int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resam
     h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
+    v.dups_valid = h->dedup_enabled ? 1 : 0;            // the kernel wrote the groups of exact duplicates (identity if it did not resample)
     if (idx_out) HIP_TRY(h, hipMemcpyAsync(idx_out, h->rs.idx, (size_t)v.P * 4, hipMemcpyDeviceToHost, h->stream));
     if (did_resample) HIP_TRY(h, hipMemcpyAsync(did_resample, h->rs.did, 4, hipMemcpyDeviceToHost, h->stream));
     if (idx_out || did_resample) return check_device_error(h);
@@ -787,6 +797,7 @@ int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int3
     h->prof_end(2);
     HIP_TRY(h, hipGetLastError());
     swap_state_buffers(h);
+    v.dups_valid = h->dedup_enabled ? 1 : 0;            // arrivals are their own representatives
     if (!by_kernel) HIP_TRY(h, hipMemcpyAsync(v.global_id, slot + v.P, (size_t)v.P * 4, hipMemcpyHostToDevice, h->stream));
     h->ring_idx.submitted(h->stream);
     return RBPF_OK;                                     // no host synchronisation; device errors surface at the next check
@@ -985,6 +996,7 @@ int rbpf_get_weights(rbpf_handle* h, double* out) {
 
 int rbpf_set_state(rbpf_handle* h, const double* poses, const double* covs, const double* weights) {
     if (!h) return RBPF_EINVAL;
+    h->v.dups_valid = 0;
     const size_t P = h->v.P;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (poses) {
@@ -1091,6 +1103,7 @@ int rbpf_get_tile(rbpf_handle* h, int32_t particle, int32_t k, double* centre2, 
 
 int rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const int8_t* cells) {
     if (!h || !cells) return RBPF_EINVAL;
+    h->v.dups_valid = 0;
     std::vector<int32_t> tab;
     int rc = fetch_tab(h, particle, tab);
     if (rc) return rc;

@@ -55,6 +55,7 @@ struct DevView {
     int mu_mode;                       // 0 = whole-fan kernel when the layout allows it, 1 = 128x128 windows only
     uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
     int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
+    int32_t* dup_of; int dups_valid;    // representative of each particle's group of exact duplicates since the last resample (kernels_resample.hip); valid until the next proposal
     int match_stage_slow;              // 1 = the matcher stages its field bit by bit (RBPF_MATCH_STAGE=slow; the check of the fast path)
     unsigned long long* stats;         // [8] device counters
     int32_t* err;                      // [1] sticky device error code
@@ -72,7 +73,7 @@ struct ResampleBuffers {
 enum { ST_RAY_CELLS = 0, ST_CELLS_WRITTEN = 1, ST_GATHERS = 2, ST_SLOW_CELLS = 3,
        ST_COPIES = 4, ST_COPY_BYTES = 5, ST_WINDOW_FALLBACKS = 6, ST_FALLBACK_REASONS = 7,
        /* 8..15: phase stamps of a -DRBPF_STAMPS build */
-       ST_NDT_RUNS = 16, ST_NDT_EVALS = 17, ST_NDT_ACCEPTED = 18, ST_COUNT = 24 };
+       ST_NDT_RUNS = 16, ST_NDT_EVALS = 17, ST_NDT_ACCEPTED = 18, ST_MATCH_SHARED = 19, ST_COUNT = 24 };
 
 }  // namespace rbpf
 
@@ -84,6 +85,7 @@ struct rbpf_handle {
     bool profiling = false;
     unsigned prof_mask = 0;                     // kernel families whose launches are bracketed by timing events (bit k = family k)
     bool have_scan = false;
+    bool dedup_enabled = true;                  // exact duplicates share one matcher run (RBPF_MATCH_DEDUP=0 turns it off)
     std::string err;
     std::vector<uint32_t> h_lut;
     std::vector<void*> allocs;
@@ -153,7 +155,7 @@ void launch_pack(const DevView& v, const void* d_jobs, int n_jobs, void* d_buf, 
 void launch_unpack(const DevView& v, const ResampleBuffers& b, const void* d_jobs, int n_jobs, const void* d_buf, hipStream_t s);
 struct PackJobHost { int32_t particle, tile, x0, x1, ya, yb; long long off; };
 struct UnpackJobHost { int32_t particle, pos, has, x0, x1, ya, yb, pad; long long off; };
-void launch_propose_weight(const DevView& v, const double* d_match, const double* d_guesses, uint8_t* d_bad,
+void launch_propose_weight(const DevView& v, const double* d_match, const int32_t* d_match_of, const double* d_guesses, uint8_t* d_bad,
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s);
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s);
 size_t match_lds_bytes(int N, int B, int n_coarse);
