@@ -233,6 +233,17 @@ def main():
 
     shard = None
     if dist is not None:
+        # RCCL sets up its peer-to-peer connections on first use, pair by pair: touch every pair (and the collectives the
+        # step uses) once before anything is timed, so that no connection is built inside the timed region
+        wt = torch.ones(1024 * world, dtype=torch.uint8, device="cuda")
+        wr = torch.empty_like(wt)
+        dist.all_to_all_single(wr, wt)
+        wi = torch.ones(256 * world, dtype=torch.int32, device="cuda")
+        dist.all_to_all_single(torch.empty_like(wi), wi)
+        wd = torch.ones(64, dtype=torch.float64, device="cuda")
+        dist.all_reduce(wd)
+        dist.broadcast(wd, src=0)
+        torch.cuda.synchronize()
         from thesis_amd.sharding import ShardedResampler
         shard = ShardedResampler(rank, world, args.particles, device=local_rank, dist=dist)
     run = Runner(args.particles, args.beams, args.cell_size, log, rank, world, shard, device=local_rank, ndt=args.ndt)
