@@ -270,6 +270,17 @@ class ShardedResampler:
         self.dist.all_to_all_single(recv, send.contiguous(), [int(x) for x in in_splits], [int(x) for x in out_splits])
         return recv.to(dev) if recv.device != dev else recv
 
+    def _all_to_all_begin(self, send, out_splits, in_splits, dtype):
+        """all_to_all that runs beside what is queued on the current stream afterwards (device transport only):
+        returns (recv, finish); finish() makes the current stream wait for the exchange."""
+        if self.host_staged or not send.is_cuda:
+            recv = self._all_to_all(send, out_splits, in_splits, dtype)
+            return recv, (lambda: None)
+        recv = self.torch.empty(int(sum(in_splits)), dtype=dtype, device=send.device)
+        work = self.dist.all_to_all_single(recv, send.contiguous(), [int(x) for x in in_splits], [int(x) for x in out_splits],
+                                           async_op=True)
+        return recv, work.wait
+
     # -- the step --------------------------------------------------------------------------------------------------------
     def _book(self, plan):
         """Ownership of every new global particle (replicated); local indices only of this rank's own particles."""
@@ -354,10 +365,14 @@ class ShardedResampler:
             b_out = [int(meta_out[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_out, ends_o)]
             b_in = [int(meta_in[e - n:e, 1].astype(np.int64).sum()) * 16 for n, e in zip(n_in, ends_i)]
             pay_send = sh.pack_raw(leaving, raw_out_h, sum(b_out))
-            # the departing particles are packed (stream order): the local part - slot pairing, state permutation, tile
-            # copies of duplicated ancestors - may now reuse their slots
+            # the departing particles are packed (stream order): the payload exchange starts, and beside it the local
+            # part - slot pairing, state permutation, tile copies of duplicated ancestors - may reuse their slots
+            if sum(b_out) + sum(b_in) > 0 or self.world > 1:
+                pay_recv, finish = self._all_to_all_begin(pay_send, b_out, b_in, torch.uint8)
+            else:
+                pay_recv, finish = sh.empty_payload(0), (lambda: None)
             sh.apply_local(plan.new_src[r], plan.new_gid[r])
-            pay_recv = self._all_to_all(pay_send, b_out, b_in, torch.uint8) if (sum(b_out) + sum(b_in) > 0 or self.world > 1) else sh.empty_payload(0)
+            finish()
         else:                                                                # shards with the one-call pack only (tests)
             # pack what leaves this rank in ONE call, ordered by destination (one gather of the metadata, one kernel);
             # the per-destination byte counts follow from the metadata rows (16-byte units in column 1)
