@@ -167,14 +167,15 @@ def _run_loop(steps, P=48, seed=5):
     return out
 
 
-def test_sharing_the_match_of_exact_duplicates_changes_nothing(monkeypatch):
+@pytest.mark.parametrize("P,steps", [(48, 25), (4608, 6)])            # the fused resample kernel, and the multi-kernel path above 4096 particles
+def test_sharing_the_match_of_exact_duplicates_changes_nothing(monkeypatch, P, steps):
     """After a resample the copies of one ancestor have the same pose, covariance and map until the next proposal
     draws their samples, so their scan matches are identical: the matcher runs once per group and the proposal reads
     the representative's result.  RBPF_MATCH_DEDUP=0 runs every particle; both must give the same bits everywhere."""
     monkeypatch.delenv("RBPF_MATCH_DEDUP", raising=False)
-    a = _run_loop(25)
+    a = _run_loop(steps, P)
     monkeypatch.setenv("RBPF_MATCH_DEDUP", "0")
-    b = _run_loop(25)
+    b = _run_loop(steps, P)
     assert a[4]["match_shared"] > 0 and b[4]["match_shared"] == 0
     for x, y in zip(a[:3], b[:3]):
         assert np.array_equal(x, y)
