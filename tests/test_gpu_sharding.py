@@ -113,6 +113,16 @@ class _OneRankDist:
         recv.copy_(send)
 
 
+def _early_vs_plain_guarded(nan_particle, q):
+    """The child process: whatever goes wrong comes back to the parent as text."""
+    import traceback
+    try:
+        _early_vs_plain(nan_particle, q)
+    except BaseException:                                   # noqa: BLE001 - the parent prints it
+        q.put("error in child:\n" + traceback.format_exc())
+        raise
+
+
 def _early_vs_plain(nan_particle, q):
     """scan_update_begin -> resample_begin -> scan_update_end -> resample_finish (weights exported, all-reduced and
     turned into ancestors on a side stream while the map update runs) gives exactly the state of scan_update +
@@ -165,7 +175,11 @@ def test_early_overlapped_resample_equals_the_plain_engine(nan_particle):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    pr = ctx.Process(target=_early_vs_plain, args=(nan_particle, q))
+    pr = ctx.Process(target=_early_vs_plain_guarded, args=(nan_particle, q))
     pr.start()
-    pr.join(300)
-    assert pr.exitcode == 0 and q.get(timeout=5) == "ok"
+    try:
+        msg = q.get(timeout=300)
+    except Exception:                                       # noqa: BLE001
+        msg = "no message from the child within 300 s"
+    pr.join(60)
+    assert msg == "ok" and pr.exitcode == 0, (msg, pr.exitcode)
