@@ -121,6 +121,10 @@ def _early_vs_plain_guarded(nan_particle, q):
     except BaseException:                                   # noqa: BLE001 - the parent prints it
         q.put("error in child:\n" + traceback.format_exc())
         raise
+    # the verdict is on its way; leave without the interpreter's teardown (the order in which torch's and the HIP
+    # runtime's globals are destroyed at exit is not what this test is about)
+    q.close(); q.join_thread()
+    os._exit(0)
 
 
 def _early_vs_plain(nan_particle, q):
