@@ -56,6 +56,8 @@ def _worker(rank, world, p_local, port, steps, q):
     dist.barrier()
     e.close()
     dist.destroy_process_group()
+    q.close(); q.join_thread()               # results delivered: leave without the interpreter's teardown (see below)
+    os._exit(0)
 
 
 @pytest.mark.parametrize("world,p_local,steps", [(2, 24, 3), (3, 40, 12)])
