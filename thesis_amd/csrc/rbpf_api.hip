@@ -725,7 +725,7 @@ int rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global, int
     const size_t need = (size_t)n_global * 4 + 16;
     if (need > h->h_early_bytes) {                       // pinned landing zone of the read-back
         if (h->h_early) HIP_TRY(h, hipHostFree(h->h_early));
-        HIP_TRY(h, hipHostMalloc(&h->h_early, need, hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc(&h->h_early, need, hipHostMallocMapped | hipHostMallocCoherent));   // a kernel writes it, the host reads it after the event: fine-grained
         h->h_early_bytes = need;
     }
     launch_resample_indices(n_global, static_cast<const double*>(d_global), u, h->cfg.resample_spread, h->d_gT, h->d_gidx,
