@@ -451,6 +451,13 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
         }
     }
     // rays ordered by falling chunk count: the rays that own a k-th chunk are perm[0 .. N_k)
+    int longer_than;                                   // lane c <= MAXLEV: rays with more than c chunks (suffix sum over the wave)
+    {
+        const int cl = lane <= MAXLEV ? s_cntc[lane] : 0;
+        int suf = cl;
+        for (int off = 1; off < 32; off <<= 1) { const int t = __shfl_down(suf, off, 64); suf += t; }   // lanes > MAXLEV hold 0
+        longer_than = suf - cl;
+    }
     for (int b0_ = 0; b0_ < v.B; b0_ += FB) {
         const int b = b0_ + tid;
         int nch = 0;
@@ -461,11 +468,8 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
             nch = (r.n + CHUNK - 1) / CHUNK;
         }
         const int pos = wave_keyed_inc(s_fill, nch, nch > 0, lane);
-        if (nch > 0) {
-            int start = 0;
-            for (int c = nch + 1; c <= MAXLEV; ++c) start += s_cntc[c];
-            perm[start + pos] = (uint16_t)b;
-        }
+        const int start = __shfl(longer_than, nch, 64);                            // rays with more chunks come first
+        if (nch > 0) perm[start + pos] = (uint16_t)b;
     }
 
     // window coordinates of a global cell of the fan / field helpers
