@@ -381,7 +381,3 @@ def main():
 
 if __name__ == "__main__":
     main()
-    # the line is out and every engine is closed: leave without the interpreter's teardown, whose destruction order of
-    # torch's, RCCL's and the HIP runtime's globals is not ours to vouch for
-    sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
