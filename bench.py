@@ -279,6 +279,8 @@ def main():
     if run.shard is not None and run.shard.timing is not None:
         print("shard timing (host s over the run):", {k: round(v, 4) for k, v in run.shard.timing.items()}, file=sys.stderr)
     if rank != 0:
+        if run.shard is not None:
+            run.shard.close()
         run.e.close()
         if dist is not None:
             dist.barrier()
@@ -345,6 +347,8 @@ def main():
         out["collective"] = {"weights": "one RCCL all-reduce of %d float64 per step" % P_total,
                              "migrated_particles_per_step": float(moved[0].item()) / (2 * max(1, args.steps + args.warmup)),
                              "migrated_bytes_per_step": float(moved[1].item()) / max(1, args.steps + args.warmup)}
+    if run.shard is not None:
+        run.shard.close()
     run.e.close()
     if world == 1:
         roofline["peak_measured_copy"] = copy_peak_gbs(torch)        # after the timed region, on an idle device

@@ -17,6 +17,8 @@
  *     retained after a call returns; device pointers handed over explicitly (the rbpf_export_* /
  *     rbpf_resample_indices_global* / rbpf_pack_* calls) are used in stream order by the work that call queues;
  *   - calls on one handle are not re-entrant; one HIP stream per handle (rbpf_set_stream);
+ *   - every call runs on the handle's device (rbpf_config.device) and leaves the caller's current
+ *     HIP device as it found it;
  *   - a soft scan-matcher failure is not an error: it is reported per particle as NaN
  *     covariance and the engine takes the reference's fallback branch (robot.py:73-78).
  *
@@ -86,8 +88,7 @@ typedef struct rbpf_counters {
     uint64_t scan_updates;        /* rbpf_scan_update/rbpf_map_update calls                       */
     uint64_t ray_cells_visited;   /* sum of Bresenham points over all rays                        */
     uint64_t cells_written;       /* unique cells written per update, summed (|W| over particles) */
-    uint64_t cells_gathered;      /* diagnostic: four 16-bit tallies of whole-fan fallback reasons
-                                     (geometry, walk tables / 8-bit guard, events, replay lists)  */
+    uint64_t cells_gathered;      /* map cells read by the weighting kernels (K*B gathers per particle-update) */
     uint64_t tiles_in_use;        /* tiles allocated from the pool (current)                      */
     uint64_t resample_copies;     /* tile copies made by resampling                               */
     uint64_t bytes_copied;        /* bytes moved by those copies (read + write)                   */
@@ -103,6 +104,12 @@ typedef struct rbpf_counters {
     uint64_t ndt_accepted;        /* runs whose pose replaced the grid pose (matchScanCustom.m:39-41) */
     uint64_t match_shared;        /* particles that took the match result of an exact duplicate (a copy made by the
                                      last resample: same pose, covariance and map) instead of repeating the search */
+    uint64_t fallback_reasons;    /* why particles left the LDS-window map update: four 16-bit tallies (geometry /
+                                     index map, counter overflow check, event tables, replay lists)               */
+    double   ms_ndt;              /* HIP-event time of the last NDT-stage kernel                  */
+    uint64_t stamp7;              /* eighth phase stamp of a -DRBPF_STAMPS diagnostic build, else 0 */
+    uint64_t map_windows;         /* LDS windows the map update processed, summed over particles (1 per particle when
+                                     the whole ray fan fits one window)                                            */
 } rbpf_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
@@ -111,7 +118,13 @@ int  rbpf_default_config(rbpf_config* cfg);
 int  rbpf_create(const rbpf_config* cfg, rbpf_handle** out);
 int  rbpf_destroy(rbpf_handle* h);
 const char* rbpf_last_error(const rbpf_handle* h);   /* h may be NULL (create failures)      */
-int  rbpf_set_stream(rbpf_handle* h, void* hip_stream); /* e.g. torch's current stream        */
+int  rbpf_set_stream(rbpf_handle* h, void* hip_stream); /* e.g. torch's current stream (borrowed: the handle
+                                                           never destroys it)                       */
+/* gives a borrowed stream back (waits for what this handle queued on it); the handle then works on a stream of its
+ * own again.  Call it before the owner of the stream goes away, or simply before rbpf_destroy. */
+int  rbpf_release_stream(rbpf_handle* h);
+/* sizeof(rbpf_config), sizeof(rbpf_counters) as this library was built: a binding checks its struct layouts */
+int  rbpf_abi_struct_bytes(int32_t* config_bytes, int32_t* counters_bytes);
 int  rbpf_synchronize(rbpf_handle* h);
 int  rbpf_get_counters(rbpf_handle* h, rbpf_counters* out);
 int  rbpf_set_profiling(rbpf_handle* h, int on);     /* per-kernel HIP events; resets the rings */

@@ -49,3 +49,33 @@ def test_bad_config_is_rejected_before_touching_the_gpu(lib):
     h = ctypes.c_void_p()
     assert lib.rbpf_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"quantum" in lib.rbpf_last_error(None)
+
+
+def test_struct_sizes_match_the_library(lib):
+    """The ctypes mirrors of rbpf_config / rbpf_counters have the layout the library was compiled with."""
+    from thesis_amd._lib import RbpfConfig, RbpfCounters
+    cb, kb = ctypes.c_int32(), ctypes.c_int32()
+    assert lib.rbpf_abi_struct_bytes(ctypes.byref(cb), ctypes.byref(kb)) == 0
+    assert (cb.value, kb.value) == (ctypes.sizeof(RbpfConfig), ctypes.sizeof(RbpfCounters))
+    hdr = open(os.path.join(REPO, "include", "rbpf_hip.h")).read()
+    body = hdr[hdr.index("typedef struct rbpf_counters {"):hdr.index("} rbpf_counters;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(?:uint64_t|double)\s+([a-z_0-9]+)(?:\[\d+\])?;", body)
+    assert names == [n for n, _ in RbpfCounters._fields_], "rbpf_counters fields: header and ctypes mirror disagree"
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """librbpf_hip.so first, torch second (the order of every test module here): both must share ONE libamdhip64,
+    or torch's streams / RCCL buffers would be handles of another runtime instance (thesis_amd/_lib.py)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from thesis_amd import _lib\n"
+            "_lib.load()\n"
+            "a = _lib.hip_runtime_paths()\n"
+            "import torch\n"
+            "b = _lib.hip_runtime_paths()\n"
+            "print(len(a), len(b), a == b)\n") % REPO
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-3:] == ["1", "1", "True"], out.stdout

@@ -178,9 +178,9 @@ def test_map_update_fan_kernel_hard_cases(eng_mod, scene):
     if scene == "one_direction":
         assert c["window_fallbacks"] == P * len(scans)      # the 8-bit guard must have fired for every particle
     if scene == "tile_corner":          # at most a particle or two over the event table; the rest ran in the four-tile window
-        assert c["window_fallbacks"] <= 2, "fallback reasons %x" % c["cells_gathered"]
+        assert c["window_fallbacks"] <= 2, "fallback reasons %x" % c["fallback_reasons"]
     if scene == "negative_side":        # only the third scan (independent random ranges: too many events) may fall back
-        assert c["window_fallbacks"] <= P, "fallback reasons %x" % c["cells_gathered"]
+        assert c["window_fallbacks"] <= P, "fallback reasons %x" % c["fallback_reasons"]
     e.close()
 
 

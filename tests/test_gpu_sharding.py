@@ -39,6 +39,7 @@ def _run_steps(engine, shard, log, steps, p_total):
 
 
 def _worker(rank, world, p_local, port, steps, q):
+    keep = _fault_log(f"rank{rank}")                        # noqa: F841
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,10 +55,9 @@ def _worker(rank, world, p_local, port, steps, q):
     tiles = [{c: cells.copy() for c, cells in e.tiles(i)} for i in range(p_local)]
     q.put((rank, gids, e.poses(), e.covs(), e.weights(), tiles, hist, sr.stats))
     dist.barrier()
+    sr.close()                               # the borrowed torch stream goes back before the engine is destroyed
     e.close()
     dist.destroy_process_group()
-    q.close(); q.join_thread()               # results delivered: leave without the interpreter's teardown (see below)
-    os._exit(0)
 
 
 @pytest.mark.parametrize("world,p_local,steps", [(2, 24, 3), (3, 40, 12)])
@@ -115,18 +115,30 @@ class _OneRankDist:
         recv.copy_(send)
 
 
+def _fault_log(tag):
+    """A fatal signal in a child (also one at interpreter exit) leaves its Python stack in gpurun_out/."""
+    import faulthandler
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        f = open(os.path.join(d, f"child_fault_{tag}_{os.getpid()}.log"), "w")
+        faulthandler.enable(f, all_threads=True)
+        return f
+    except OSError:
+        faulthandler.enable()
+        return None
+
+
 def _early_vs_plain_guarded(nan_particle, q):
-    """The child process: whatever goes wrong comes back to the parent as text."""
+    """The child process: whatever goes wrong comes back to the parent as text; the process then ends the ordinary
+    way (interpreter teardown included), and the parent checks its exit code."""
     import traceback
+    keep = _fault_log("early")                              # noqa: F841 - the file stays open until the process ends
     try:
         _early_vs_plain(nan_particle, q)
     except BaseException:                                   # noqa: BLE001 - the parent prints it
         q.put("error in child:\n" + traceback.format_exc())
         raise
-    # the verdict is on its way; leave without the interpreter's teardown (the order in which torch's and the HIP
-    # runtime's globals are destroyed at exit is not what this test is about)
-    q.close(); q.join_thread()
-    os._exit(0)
 
 
 def _early_vs_plain(nan_particle, q):
@@ -171,6 +183,7 @@ def _early_vs_plain(nan_particle, q):
     for p in (0, 5, P - 1):
         for (ca, ta), (cb, tb) in zip(a.tiles(p), b.tiles(p)):
             assert ca == cb and np.array_equal(ta, tb)
+    rs.close()                              # drops the early tensors, gives torch's stream back
     a.close(); b.close()
     q.put("ok")
 
@@ -189,3 +202,30 @@ def test_early_overlapped_resample_equals_the_plain_engine(nan_particle):
         msg = "no message from the child within 300 s"
     pr.join(60)
     assert msg == "ok" and pr.exitcode == 0, (msg, pr.exitcode)
+
+
+def test_engine_leaves_current_device_and_borrowed_stream_alone():
+    """rbpf_create and every later call restore the caller's current device; a borrowed torch stream is released
+    (not destroyed) by close(), and torch can go on using it."""
+    import torch
+    from thesis_amd.engine import ParticleEngine
+    from thesis_amd.datasets import synthetic
+    torch.cuda.init()
+    dev0 = torch.cuda.current_device()
+    side = torch.cuda.Stream()
+    e = ParticleEngine(8, max_beams=181, pool_tiles=32)
+    assert torch.cuda.current_device() == dev0
+    ang = synthetic.beam_angles(181, np.pi)
+    r = synthetic.cast_scan((0.0, 0.0, 0.0), ang, np.random.Generator(np.random.PCG64(0)))
+    e.set_stream(side.cuda_stream)
+    e.set_scan(r, ang)
+    e.map_update(np.zeros((8, 3)))
+    assert torch.cuda.current_device() == dev0
+    e.release_stream()
+    e.map_update(np.zeros((8, 3)))                       # works on a stream of its own again
+    e.set_stream(side.cuda_stream)
+    e.close()                                            # releases the stream first
+    with torch.cuda.stream(side):                        # the stream is still torch's and still works
+        t = torch.ones(1024, device="cuda") * 2
+    side.synchronize()
+    assert float(t.sum().item()) == 2048.0

@@ -37,6 +37,7 @@ class RbpfCounters(C.Structure):
         ("ms_match", C.c_double), ("ms_resample", C.c_double), ("slow_cells", C.c_uint64),
         ("reserved", C.c_uint64 * 7), ("window_fallbacks", C.c_uint64), ("ndt_runs", C.c_uint64), ("ndt_evaluations", C.c_uint64),
         ("ndt_accepted", C.c_uint64), ("match_shared", C.c_uint64),
+        ("fallback_reasons", C.c_uint64), ("ms_ndt", C.c_double), ("stamp7", C.c_uint64), ("map_windows", C.c_uint64),
     ]
 
 
@@ -53,6 +54,8 @@ PROTOTYPES = {
     "rbpf_destroy": (C.c_int, [_H]),
     "rbpf_last_error": (C.c_char_p, [_H]),
     "rbpf_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "rbpf_release_stream": (C.c_int, [_H]),
+    "rbpf_abi_struct_bytes": (C.c_int, [_I, _I]),
     "rbpf_synchronize": (C.c_int, [_H]),
     "rbpf_get_counters": (C.c_int, [_H, C.POINTER(RbpfCounters)]),
     "rbpf_set_profiling": (C.c_int, [_H, C.c_int]),
@@ -102,6 +105,42 @@ PROTOTYPES = {
 _lib = None
 
 
+def hip_runtime_paths():
+    """Files of every libamdhip64 mapped into this process (there must never be two: see _share_torch_hip_runtime)."""
+    out = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    out.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(out)
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  torch wheels for ROCm carry their own libamdhip64.so (soname libamdhip64.so.7, found
+    through libtorch_hip's RPATH under the name libamdhip64.so), librbpf_hip.so is linked against /opt/rocm's
+    libamdhip64.so.7.  If torch is imported first, the loader resolves our dependency to torch's copy by soname; if
+    librbpf_hip.so comes first, /opt/rocm's copy is mapped and a later `import torch` maps a SECOND runtime, because
+    the name it asks for matches neither the path nor the soname of the first.  Streams, events and device pointers
+    that cross between torch and the engine (sharding.py: torch's current stream, RCCL buffers) are then handles of
+    another runtime instance, and torch.cuda.synchronize() no longer waits for the engine's kernels.  So when torch is
+    installed and no HIP runtime is mapped yet, torch's copy is loaded here first; torch finds the very same file later."""
+    if hip_runtime_paths():
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 def load() -> C.CDLL:
     """Load librbpf_hip.so; raise if it is missing (there is no fallback path)."""
     global _lib
@@ -111,7 +150,15 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -m thesis_amd.build`); thesis_amd has no CPU fallback")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    cb, kb = C.c_int32(), C.c_int32()
+    fn = lib.rbpf_abi_struct_bytes
+    fn.restype, fn.argtypes = C.c_int, [_I, _I]
+    fn(C.byref(cb), C.byref(kb))
+    if cb.value != C.sizeof(RbpfConfig) or kb.value != C.sizeof(RbpfCounters):
+        raise ImportError(f"{LIB_PATH} was built from another include/rbpf_hip.h (struct sizes {cb.value}/{kb.value} vs "
+                          f"{C.sizeof(RbpfConfig)}/{C.sizeof(RbpfCounters)}): run `python -m thesis_amd.build --force`")
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res

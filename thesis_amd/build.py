@@ -20,29 +20,52 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+def _newer(path: str, t: float) -> bool:
+    return os.path.getmtime(path) > t
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(_newer(d, t) for d in deps)
 
 
 def build_extension(force: bool = False, verbose: bool = True) -> str:
+    """Compiles what changed (a source is recompiled when it, a header or this script is newer than its object;
+    sources compile in parallel) and links."""
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = []   # diagnostic builds: per-phase cycle stamps in ONE kernel (RBPF_STAMPS=mapupdate | match)
-    stamp_target = os.environ.get("RBPF_STAMPS", "")
-    objs = []
+    stamp_target = os.environ.get("RBPF_STAMPS", "")   # diagnostic builds: per-phase cycle stamps in ONE kernel file (mapfan | mapupdate | mapray | match)
+    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        extra = ["-DRBPF_STAMPS"] if stamp_target and stamp_target in src else []
-        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        stamped = bool(stamp_target) and stamp_target in src
+        fresh = os.path.exists(obj) and not any(_newer(d, os.path.getmtime(obj)) for d in [path] + common)
+        if fresh and not force and not stamped and not os.path.exists(obj + ".stamped"):
+            continue
+        extra = ["-DRBPF_STAMPS"] if stamped else []
+        jobs.append(([hipcc, *FLAGS, *extra, "-c", path, "-o", obj], obj, stamped))
+
+    def run(job):
+        cmd, obj, stamped = job
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+        marker = obj + ".stamped"                       # a stamped object must not survive into a normal build
+        if stamped:
+            open(marker, "w").close()
+        elif os.path.exists(marker):
+            os.remove(marker)
+
+    with ThreadPoolExecutor(max(1, min(len(jobs), int(os.environ.get("RBPF_BUILD_JOBS", "6"))))) as ex:
+        list(ex.map(run, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

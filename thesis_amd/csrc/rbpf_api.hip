@@ -24,6 +24,19 @@ static thread_local std::string g_create_err;
         }                                                                                          \
     } while (0)
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it (a process may
+// hold engines on several GPUs, and torch keeps its own notion of the current device).
+struct DevGuard {
+    int prev = -1; bool switched = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) { if (hipSetDevice(dev) == hipSuccess) switched = prev >= 0; else (void)hipGetLastError(); }
+    }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete; DevGuard& operator=(const DevGuard&) = delete;
+};
+#define ON_DEVICE(h) DevGuard dev_guard_((h)->cfg.device)
+
 static int fail(rbpf_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
@@ -130,9 +143,12 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         return fail(nullptr, RBPF_EINVAL, "log-odds constants have the wrong sign");
     cc.thr = (int)floor(c.occupied_threshold / c.quantum + 1e-9);
 
-    hipError_t e = hipSetDevice(c.device);
-    if (e != hipSuccess) return fail(nullptr, RBPF_EDEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e) +
-                                     " (librbpf_hip needs an MI355X; there is no CPU path)");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e == hipSuccess && (c.device < 0 || c.device >= n_dev)) e = hipErrorInvalidDevice;
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, RBPF_EDEVICE, std::string("device ") + std::to_string(c.device) + ": " + hipGetErrorString(e) +
+                                     " (librbpf_hip needs an MI355X; there is no CPU path)"); }
+    DevGuard dev_guard_(c.device);         // the caller's current device is restored on return
 
     rbpf_handle* h = new rbpf_handle();
     h->cfg = c;
@@ -282,28 +298,35 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
     return RBPF_OK;
 }
 
+// Teardown order: (1) everything queued on the handle's stream has finished; (2) every event that guards host memory
+// a kernel or a copy may still touch has completed - the early read-back and the pinned rings can be in use by work on
+// ANOTHER stream (rbpf_resample_indices_global_early takes one); (3) device memory, pinned memory, events; (4) the
+// stream, only if the handle created it.  A borrowed stream (rbpf_set_stream) is synchronised once and otherwise left
+// alone: it belongs to the caller and may already be gone when a late destructor runs.
 int rbpf_destroy(rbpf_handle* h) {
     if (!h) return RBPF_OK;
-    (void)hipStreamSynchronize(h->stream);              // nullptr = the default stream
-    for (void* p : h->allocs) hipFree(p);
-    if (h->d_guess) hipFree(h->d_guess);
-    if (h->d_prs) hipFree(h->d_prs);
-    if (h->d_w) hipFree(h->d_w);
-    if (h->d_gT) hipFree(h->d_gT);
-    if (h->d_gidx) hipFree(h->d_gidx);
-    if (h->d_i32) hipFree(h->d_i32);
-    if (h->d_jobs) hipFree(h->d_jobs);
-    if (h->ev_weights) hipEventDestroy(h->ev_weights);
-    if (h->ev_jobs) hipEventDestroy(h->ev_jobs);
-    if (h->h_jobs) hipHostFree(h->h_jobs);
-    if (h->ev_early) hipEventDestroy(h->ev_early);
-    if (h->h_early) hipHostFree(h->h_early);
+    ON_DEVICE(h);
+    if (h->stream || h->own_stream) { if (hipStreamSynchronize(h->stream) != hipSuccess) (void)hipGetLastError(); }
+    else if (hipStreamSynchronize(nullptr) != hipSuccess) (void)hipGetLastError();       // borrowed null stream
+    auto wait_ev = [](hipEvent_t ev) { if (ev && hipEventSynchronize(ev) != hipSuccess) (void)hipGetLastError(); };
+    if (h->early_n > 0 || h->h_early) wait_ev(h->ev_early);
+    if (h->h_jobs_used) wait_ev(h->ev_jobs);
+    if (h->ev_weights_valid) wait_ev(h->ev_weights);
+    for (rbpf_handle::PinnedRing* r : {&h->ring_scan, &h->ring_last, &h->ring_idx})
+        for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) if (r->used[i]) wait_ev(r->ev[i]);
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : {(void*)h->d_guess, (void*)h->d_prs, (void*)h->d_w, (void*)h->d_gT, (void*)h->d_gidx, (void*)h->d_i32, (void*)h->d_jobs})
+        if (p) (void)hipFree(p);
+    if (h->h_jobs) (void)hipHostFree(h->h_jobs);
+    if (h->h_early) (void)hipHostFree(h->h_early);
     for (rbpf_handle::PinnedRing* r : {&h->ring_scan, &h->ring_last, &h->ring_idx}) {
-        if (r->base) hipHostFree(r->base);
-        for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
+        if (r->base) (void)hipHostFree(r->base);
+        for (int i = 0; i < rbpf_handle::PinnedRing::N; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
     }
+    for (hipEvent_t ev : {h->ev_weights, h->ev_jobs, h->ev_early}) if (ev) (void)hipEventDestroy(ev);
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) for (int e = 0; e < 2; ++e) for (auto& ev : h->ring[k][e]) if (ev) (void)hipEventDestroy(ev);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    (void)hipGetLastError();
     delete h;
     return RBPF_OK;
 }
@@ -312,25 +335,51 @@ const char* rbpf_last_error(const rbpf_handle* h) { return h ? h->err.c_str() : 
 
 int rbpf_set_stream(rbpf_handle* h, void* s) {
     if (!h) return RBPF_EINVAL;
-    (void)hipStreamSynchronize(h->stream);              // nullptr = the default stream
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    ON_DEVICE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));        // nullptr = the default stream
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->own_stream = false;
     h->stream = static_cast<hipStream_t>(s);
+    h->last_end = nullptr;
+    return RBPF_OK;
+}
+
+// gives a borrowed stream back: everything queued on it by this handle has finished when the call returns, and the
+// handle works on a stream of its own again (as after rbpf_create)
+int rbpf_release_stream(rbpf_handle* h) {
+    if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
+    if (h->own_stream) return RBPF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->early_n > 0) HIP_TRY(h, hipEventSynchronize(h->ev_early));
+    h->stream = nullptr;
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    h->last_end = nullptr;
+    return RBPF_OK;
+}
+
+int rbpf_abi_struct_bytes(int32_t* config_bytes, int32_t* counters_bytes) {
+    if (config_bytes) *config_bytes = (int32_t)sizeof(rbpf_config);
+    if (counters_bytes) *counters_bytes = (int32_t)sizeof(rbpf_counters);
     return RBPF_OK;
 }
 
 int rbpf_synchronize(rbpf_handle* h) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     return check_device_error(h);
 }
 
 int rbpf_set_profiling_families(rbpf_handle* h, uint32_t mask) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     return rbpf_set_profiling(h, mask ? (int)(0x100u | (mask & 0x1Fu)) : 0);
 }
 
 int rbpf_set_profiling(rbpf_handle* h, int on) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     h->profiling = on != 0;
     h->prof_mask = !on ? 0u : (on & 0x100) ? ((unsigned)on & 0x1Fu) : 0x1Fu;
     for (int k = 0; k < rbpf_handle::N_KERN; ++k) h->ring_n[k] = 0;
@@ -341,6 +390,7 @@ int rbpf_set_profiling(rbpf_handle* h, int on) {
 
 int rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t cap, int32_t* n_out) {
     if (!h || !n_out || which < 0 || which >= rbpf_handle::N_KERN) return RBPF_EINVAL;
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     int n = std::min(h->ring_n[which], rbpf_handle::RING);
     int first = h->ring_n[which] - n;
@@ -358,6 +408,7 @@ int rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t ca
 
 int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     if (!h || !out) return RBPF_EINVAL;
+    ON_DEVICE(h);
     unsigned long long st[ST_COUNT];
     int32_t top = 0;
     HIP_TRY(h, hipMemcpyAsync(st, h->v.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -373,11 +424,12 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.ndt_runs = st[ST_NDT_RUNS]; c.ndt_evaluations = st[ST_NDT_EVALS]; c.ndt_accepted = st[ST_NDT_ACCEPTED];
     c.match_shared = st[ST_MATCH_SHARED];
     for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];
-    // diagnostic slot: four 16-bit tallies of whole-fan fallback reasons, or the eighth phase stamp of a -DRBPF_STAMPS build
-    c.cells_gathered = st[15] ? st[15] : st[ST_FALLBACK_REASONS];
+    c.stamp7 = st[15];
+    c.fallback_reasons = st[ST_FALLBACK_REASONS];
+    c.map_windows = st[ST_MAP_WINDOWS];
     if (h->profiling) {
-        double* dst[4] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match};
-        for (int k = 0; k < 4; ++k) {
+        double* dst[5] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match, &c.ms_ndt};
+        for (int k = 0; k < 5; ++k) {
             if (h->ring_n[k] == 0) continue;
             int slot = (h->ring_n[k] - 1) % rbpf_handle::RING;
             float ms = 0;
@@ -392,6 +444,7 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
 // ---- a1 ---------------------------------------------------------------------------------------------
 int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, int32_t B) {
     if (!h || !ranges || !angles) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (B < 1 || B > h->cfg.max_beams) return fail(h, RBPF_EINVAL, "n_beams out of range");
     const rbpf_config& c = h->cfg;
     const size_t MBP = ((size_t)c.max_beams + 15) & ~(size_t)15;
@@ -433,6 +486,7 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
 // ---- a2 ---------------------------------------------------------------------------------------------
 int rbpf_imu_update(rbpf_handle* h, int32_t model, const double* d, double dt_ticks) {
     if (!h || !d) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (model < 0 || model > 2) return fail(h, RBPF_EINVAL, "unknown motion model");
     launch_imu_update(h->v, model, d[0], d[1], d[2], dt_ticks, h->cfg.vel_noise, h->stream);
     HIP_TRY(h, hipGetLastError());
@@ -452,6 +506,7 @@ static int ensure_sample_buffers(rbpf_handle* h, size_t n) {
 
 int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs, int32_t K, double* out_w) {
     if (!h || !guesses || !prs || !out_w) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     if (K < 1 || K > 32) return fail(h, RBPF_EINVAL, "n_samples must be in 1..32");
     const size_t n = (size_t)h->v.P * K;
@@ -480,6 +535,7 @@ static int run_map_update(rbpf_handle* h, const uint8_t* d_bad = nullptr) {
 
 int rbpf_map_update(rbpf_handle* h, const double* poses) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     h->v.dups_valid = 0;
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     DevView& v = h->v;
@@ -538,6 +594,7 @@ int rbpf_scan_update(rbpf_handle* h, int32_t adj, const double* last_scan_xy, in
 int rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_xy, int32_t n_last,
                            const double* match_override, const double* guesses) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     DevView& v = h->v;
     const size_t P = v.P;
@@ -570,6 +627,7 @@ int rbpf_scan_update_begin(rbpf_handle* h, int32_t adj, const double* last_scan_
 // second half: the map update at the new mean pose and the NaN-covariance branch (robot.py:115, 73-78)
 int rbpf_scan_update_end(rbpf_handle* h) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!h->scan_begun) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
     h->scan_begun = false;
     // HybridMap.update at the new mean pose (robot.py:115), then - in the same launch - the robot.py:73-78 weight
@@ -582,6 +640,7 @@ int rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const
                     const double* guess3, int32_t cells_per_m, const double* pose_range3, double* pose_out3,
                     double* cov_out9, double* score_out) {
     if (!h || !curr_xy || !guess3 || !pose_range3 || !pose_out3 || !cov_out9 || !score_out) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (n_curr < 0 || n_curr > h->cfg.max_beams || n_ref < 0 || (n_ref > 0 && !ref_xy)) return fail(h, RBPF_EINVAL, "point counts out of range");
     if (cells_per_m < 1) return fail(h, RBPF_EINVAL, "cells_per_m must be >= 1");
     rbpf_config c = h->cfg;
@@ -625,6 +684,7 @@ int rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const
 int rbpf_match_inputs(rbpf_handle* h, int32_t particle, const double* guess3, double* curr_xy, int32_t* n_curr,
                       double* ref_xy, int32_t* n_ref, int32_t cap_ref) {
     if (!h || !guess3 || !curr_xy || !n_curr || !ref_xy || !n_ref || cap_ref < 0) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     DevView& v = h->v;
     if (particle < 0 || particle >= v.P) return fail(h, RBPF_EINVAL, "particle index out of range");
@@ -668,6 +728,7 @@ static void swap_state_buffers(rbpf_handle* h) {
 
 int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resample) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     DevView& v = h->v;
     if (u != u) u = internal_uniform(h);
     if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
@@ -686,6 +747,7 @@ int rbpf_resample(rbpf_handle* h, double u, int32_t* idx_out, int32_t* did_resam
 // ---- multi-GPU pieces: one handle per rank, the collectives are the caller's (RCCL) ---------------------------------
 int rbpf_set_global_ids(rbpf_handle* h, const int32_t* ids) {
     if (!h || !ids) return RBPF_EINVAL;
+    ON_DEVICE(h);
     HIP_TRY(h, hipMemcpyAsync(h->v.global_id, ids, (size_t)h->v.P * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RBPF_OK;
@@ -693,6 +755,7 @@ int rbpf_set_global_ids(rbpf_handle* h, const int32_t* ids) {
 
 int rbpf_export_weights(rbpf_handle* h, void* d_global, int32_t n_global) {
     if (!h || !d_global || n_global < h->v.P) return RBPF_EINVAL;
+    ON_DEVICE(h);
     launch_export_weights(h->v, static_cast<double*>(d_global), n_global, nullptr, h->stream);
     HIP_TRY(h, hipGetLastError());
     return RBPF_OK;                                     // stream-ordered: see the header about collectives on other streams
@@ -700,6 +763,7 @@ int rbpf_export_weights(rbpf_handle* h, void* d_global, int32_t n_global) {
 
 int rbpf_export_weights_early(rbpf_handle* h, void* d_global, int32_t n_global, void* aux_stream) {
     if (!h || !d_global || n_global < h->v.P) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!h->begin_seen) return fail(h, RBPF_ESTATE, "rbpf_scan_update_begin has not been called");
     hipStream_t s = static_cast<hipStream_t>(aux_stream);
     if (s != h->stream) {                                 // same stream: stream order is the ordering
@@ -716,6 +780,7 @@ int rbpf_export_weights_early(rbpf_handle* h, void* d_global, int32_t n_global, 
 
 int rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global, int32_t n_global, double u, void* aux_stream) {
     if (!h || !d_global || n_global < 1) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
     hipStream_t s = static_cast<hipStream_t>(aux_stream);
     int rc = scratch(h, &h->d_gT, &h->d_gT_cap, (size_t)n_global);
@@ -725,7 +790,9 @@ int rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global, int
     const size_t need = (size_t)n_global * 4 + 16;
     if (need > h->h_early_bytes) {                       // pinned landing zone of the read-back
         if (h->h_early) HIP_TRY(h, hipHostFree(h->h_early));
-        HIP_TRY(h, hipHostMalloc(&h->h_early, need, hipHostMallocMapped | hipHostMallocCoherent));   // a kernel writes it, the host reads it after the event: fine-grained
+        // a kernel writes it through its device address, the host reads it after ev_early, which is created WITHOUT
+        // hipEventDisableSystemFence and so releases at system scope: plain pinned memory is enough
+        HIP_TRY(h, hipHostMalloc(&h->h_early, need, hipHostMallocDefault));
         h->h_early_bytes = need;
     }
     launch_resample_indices(n_global, static_cast<const double*>(d_global), u, h->cfg.resample_spread, h->d_gT, h->d_gidx,
@@ -748,6 +815,7 @@ int rbpf_resample_indices_global_early(rbpf_handle* h, const void* d_global, int
 
 int rbpf_resample_indices_global_wait(rbpf_handle* h, int32_t* idx_out, int32_t* did_resample, double* nan_branch_ranks) {
     if (!h || !idx_out || !did_resample || !nan_branch_ranks) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (h->early_n <= 0) return fail(h, RBPF_ESTATE, "rbpf_resample_indices_global_early has not been called");
     HIP_TRY(h, hipEventSynchronize(h->ev_early));        // only up to the read-back, not the work queued after it
     const unsigned char* src = static_cast<const unsigned char*>(h->h_early);
@@ -761,6 +829,7 @@ int rbpf_resample_indices_global_wait(rbpf_handle* h, int32_t* idx_out, int32_t*
 int rbpf_resample_indices_global(rbpf_handle* h, const void* d_global, int32_t n_global, double u, int32_t* idx_out,
                                  int32_t* did_resample) {
     if (!h || !d_global || !idx_out || !did_resample || n_global < 1) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!(u >= 0.0 && u < 1.0)) return fail(h, RBPF_EINVAL, "u must lie in [0, 1)");
     int rc = scratch(h, &h->d_gT, &h->d_gT_cap, (size_t)n_global);
     if (rc) return rc;
@@ -776,6 +845,7 @@ int rbpf_resample_indices_global(rbpf_handle* h, const void* d_global, int32_t n
 
 int rbpf_apply_resample_local(rbpf_handle* h, const int32_t* new_src, const int32_t* new_global_id) {
     if (!h || !new_src || !new_global_id) return RBPF_EINVAL;
+    ON_DEVICE(h);
     DevView& v = h->v;
     // sources must be sorted ascending with the arrivals (-1) last: duplicates of one ancestor are then adjacent
     for (int j = 1; j < v.P; ++j) {
@@ -867,6 +937,7 @@ static int64_t layout_packed(const DevView& v, const int32_t* g, int n, const in
 int rbpf_pack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_buf, int64_t cap_bytes,
                         int32_t* meta_out, int64_t* bytes_out) {
     if (!h || n < 0 || !bytes_out || (n > 0 && (!local_idx || !d_buf || !meta_out))) return RBPF_EINVAL;
+    ON_DEVICE(h);
     *bytes_out = 0;
     if (n == 0) return RBPF_OK;
     DevView& v = h->v;
@@ -899,6 +970,7 @@ int32_t rbpf_pack_raw_width(rbpf_handle* h) { return h ? 5 * h->v.L * h->v.L : -
 
 int rbpf_gather_pack_meta(rbpf_handle* h, const int32_t* local_idx, int32_t n, void* d_raw) {
     if (!h || n < 0 || (n > 0 && (!local_idx || !d_raw))) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (n == 0) return RBPF_OK;
     DevView& v = h->v;
     if (n > v.P) return fail(h, RBPF_EINVAL, "more departing particles than particles");
@@ -925,6 +997,7 @@ int rbpf_meta_from_raw(rbpf_handle* h, const int32_t* raw, int32_t n, int32_t* m
 int rbpf_pack_particles_raw(rbpf_handle* h, const int32_t* local_idx, int32_t n, const int32_t* raw, void* d_buf,
                             int64_t cap_bytes, int64_t* bytes_out) {
     if (!h || n < 0 || !bytes_out || (n > 0 && (!local_idx || !raw || !d_buf))) return RBPF_EINVAL;
+    ON_DEVICE(h);
     *bytes_out = 0;
     if (n == 0) return RBPF_OK;
     DevView& v = h->v;
@@ -943,6 +1016,7 @@ int rbpf_pack_particles_raw(rbpf_handle* h, const int32_t* local_idx, int32_t n,
 // installs n received particles at the given local indices (after rbpf_apply_resample_local); weight <- 1.0 (main.py:77-78)
 int rbpf_unpack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, const void* d_buf, const int32_t* meta_in) {
     if (!h || n < 0 || (n > 0 && (!local_idx || !d_buf || !meta_in))) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (n == 0) return RBPF_OK;
     DevView& v = h->v;
     const int LL = v.L * v.L, W = 2 + 6 * LL;
@@ -968,6 +1042,7 @@ int rbpf_unpack_particles(rbpf_handle* h, const int32_t* local_idx, int32_t n, c
 // ---- state access -----------------------------------------------------------------------------------------
 int rbpf_get_poses(rbpf_handle* h, double* out) {
     if (!h || !out) return RBPF_EINVAL;
+    ON_DEVICE(h);
     const size_t P = h->v.P;
     std::vector<double> t(3 * P);
     HIP_TRY(h, hipMemcpyAsync(t.data(), h->v.px, P * 8, hipMemcpyDeviceToHost, h->stream));
@@ -980,6 +1055,7 @@ int rbpf_get_poses(rbpf_handle* h, double* out) {
 
 int rbpf_get_covs(rbpf_handle* h, double* out) {
     if (!h || !out) return RBPF_EINVAL;
+    ON_DEVICE(h);
     const size_t P = h->v.P;
     std::vector<double> t(9 * P);
     HIP_TRY(h, hipMemcpyAsync(t.data(), h->v.cov, 9 * P * 8, hipMemcpyDeviceToHost, h->stream));
@@ -990,12 +1066,14 @@ int rbpf_get_covs(rbpf_handle* h, double* out) {
 
 int rbpf_get_weights(rbpf_handle* h, double* out) {
     if (!h || !out) return RBPF_EINVAL;
+    ON_DEVICE(h);
     HIP_TRY(h, hipMemcpyAsync(out, h->v.weight, (size_t)h->v.P * 8, hipMemcpyDeviceToHost, h->stream));
     return check_device_error(h);
 }
 
 int rbpf_set_state(rbpf_handle* h, const double* poses, const double* covs, const double* weights) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     h->v.dups_valid = 0;
     const size_t P = h->v.P;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1034,6 +1112,7 @@ static int fetch_tab(rbpf_handle* h, int32_t particle, std::vector<int32_t>& tab
 
 int rbpf_refresh_last_scan(rbpf_handle* h, int32_t particle) {
     if (!h) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (!h->have_scan) return fail(h, RBPF_ESTATE, "rbpf_set_scan has not been called");
     if (particle < 0 || particle >= h->v.P) return fail(h, RBPF_EINVAL, "particle out of range");
     launch_last_scan(h->v, particle, h->d_last_xy, h->stream);
@@ -1044,6 +1123,7 @@ int rbpf_refresh_last_scan(rbpf_handle* h, int32_t particle) {
 
 int rbpf_export_last_scan(rbpf_handle* h, void* d_out_xy, int32_t* n_points) {
     if (!h || !d_out_xy || !n_points) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (h->n_last_dev < 0) return fail(h, RBPF_ESTATE, "no device-resident previous scan");
     HIP_TRY(h, hipMemcpyAsync(d_out_xy, h->d_last_xy, (size_t)h->n_last_dev * 16, hipMemcpyDeviceToDevice, h->stream));
     *n_points = h->n_last_dev;
@@ -1052,6 +1132,7 @@ int rbpf_export_last_scan(rbpf_handle* h, void* d_out_xy, int32_t* n_points) {
 
 int rbpf_import_last_scan(rbpf_handle* h, const void* d_xy, int32_t n_points) {
     if (!h || !d_xy || n_points < 0 || n_points > h->cfg.max_beams) return RBPF_EINVAL;
+    ON_DEVICE(h);
     HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, d_xy, (size_t)n_points * 16, hipMemcpyDeviceToDevice, h->stream));
     h->n_last_dev = n_points;
     return RBPF_OK;
@@ -1071,6 +1152,7 @@ int rbpf_set_rng_state(rbpf_handle* h, uint64_t scan_updates, uint64_t resample_
 
 int rbpf_get_tile_count(rbpf_handle* h, int32_t particle, int32_t* out_n) {
     if (!h || !out_n) return RBPF_EINVAL;
+    ON_DEVICE(h);
     std::vector<int32_t> tab;
     int rc = fetch_tab(h, particle, tab);
     if (rc) return rc;
@@ -1082,6 +1164,7 @@ int rbpf_get_tile_count(rbpf_handle* h, int32_t particle, int32_t* out_n) {
 
 int rbpf_get_tile(rbpf_handle* h, int32_t particle, int32_t k, double* centre2, int8_t* cells) {
     if (!h || !centre2 || !cells) return RBPF_EINVAL;
+    ON_DEVICE(h);
     std::vector<int32_t> tab;
     int rc = fetch_tab(h, particle, tab);
     if (rc) return rc;
@@ -1103,6 +1186,7 @@ int rbpf_get_tile(rbpf_handle* h, int32_t particle, int32_t k, double* centre2, 
 
 int rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const int8_t* cells) {
     if (!h || !cells) return RBPF_EINVAL;
+    ON_DEVICE(h);
     h->v.dups_valid = 0;
     std::vector<int32_t> tab;
     int rc = fetch_tab(h, particle, tab);
@@ -1143,6 +1227,7 @@ int rbpf_set_tile(rbpf_handle* h, int32_t particle, double cx, double cy, const 
 
 int rbpf_get_odds_at(rbpf_handle* h, int32_t particle, const double* xy, int32_t n, double* out_vals, uint8_t* out_none) {
     if (!h || !xy || !out_vals || !out_none || n < 0) return RBPF_EINVAL;
+    ON_DEVICE(h);
     if (particle < 0 || particle >= h->v.P) return fail(h, RBPF_EINVAL, "particle index out of range");
     if (n == 0) return RBPF_OK;
     double *d_xy = nullptr, *d_v = nullptr; uint8_t* d_n = nullptr;

@@ -73,7 +73,7 @@ struct ResampleBuffers {
 enum { ST_RAY_CELLS = 0, ST_CELLS_WRITTEN = 1, ST_GATHERS = 2, ST_SLOW_CELLS = 3,
        ST_COPIES = 4, ST_COPY_BYTES = 5, ST_WINDOW_FALLBACKS = 6, ST_FALLBACK_REASONS = 7,
        /* 8..15: phase stamps of a -DRBPF_STAMPS build */
-       ST_NDT_RUNS = 16, ST_NDT_EVALS = 17, ST_NDT_ACCEPTED = 18, ST_MATCH_SHARED = 19, ST_COUNT = 24 };
+       ST_NDT_RUNS = 16, ST_NDT_EVALS = 17, ST_NDT_ACCEPTED = 18, ST_MATCH_SHARED = 19, ST_MAP_WINDOWS = 20, ST_COUNT = 24 };
 
 }  // namespace rbpf
 

@@ -6,7 +6,10 @@ librbpf_hip.so (include/rbpf_hip.h); numpy arrays cross the boundary as plain po
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import sys
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -33,6 +36,22 @@ class RbpfError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"librbpf_hip error {code}: {msg}")
         self.code = code
+
+
+# Engines still open when the interpreter exits are closed from an atexit hook, i.e. while the HIP runtime (and torch,
+# whose stream an engine may have borrowed) is still alive; __del__ never touches the GPU during interpreter shutdown.
+_LIVE = weakref.WeakSet()
+
+
+def _close_all_engines():
+    for e in list(_LIVE):
+        try:
+            e.close()
+        except Exception:                                    # noqa: BLE001 - nothing useful can be done at exit
+            pass
+
+
+atexit.register(_close_all_engines)
 
 
 class ParticleEngine:
@@ -66,6 +85,8 @@ class ParticleEngine:
         self._check(self._lib.rbpf_get_dim(self._h, C.byref(d)))
         self.dim = d.value
         self.n_beams = 0
+        self._borrowed_stream = False
+        _LIVE.add(self)
 
     # -- plumbing ------------------------------------------------------------------------------------
     def _check(self, rc: int, h="self"):
@@ -74,18 +95,32 @@ class ParticleEngine:
             raise RbpfError(rc, (self._lib.rbpf_last_error(hh) or b"").decode())
 
     def close(self):
+        """Releases a borrowed stream first (waits for what the engine queued on it), then destroys the handle."""
         if getattr(self, "_h", None) and self._h.value:
+            if self._borrowed_stream:
+                self._lib.rbpf_release_stream(self._h)
+                self._borrowed_stream = False
             self._lib.rbpf_destroy(self._h)
             self._h = C.c_void_p()
+        _LIVE.discard(self)
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():               # interpreter shutdown: the atexit hook has run already
+            return
         try:
             self.close()
-        except Exception:
+        except Exception:                                    # noqa: BLE001
             pass
 
     def set_stream(self, stream_ptr: int):
+        """Work on the caller's stream from now on (borrowed: never destroyed by the engine)."""
         self._check(self._lib.rbpf_set_stream(self._h, C.c_void_p(stream_ptr)))
+        self._borrowed_stream = True
+
+    def release_stream(self):
+        """Give a borrowed stream back; the engine works on a stream of its own again."""
+        self._check(self._lib.rbpf_release_stream(self._h))
+        self._borrowed_stream = False
 
     def synchronize(self):
         self._check(self._lib.rbpf_synchronize(self._h))
@@ -114,8 +149,8 @@ class ParticleEngine:
     def counters(self) -> Dict[str, float]:
         c = RbpfCounters()
         self._check(self._lib.rbpf_get_counters(self._h, C.byref(c)))
-        out = {k: getattr(c, k) for k, _ in RbpfCounters._fields_ if k != "reserved"}
-        out["stamps"] = list(c.reserved)
+        out = {k: getattr(c, k) for k, _ in RbpfCounters._fields_ if k not in ("reserved", "stamp7")}
+        out["stamps"] = list(c.reserved) + [c.stamp7]        # eight phase stamps of a -DRBPF_STAMPS build, else zeros
         return out
 
     # -- a1 ------------------------------------------------------------------------------------------

@@ -106,6 +106,15 @@ class EngineShard:
         self.stream = torch.cuda.current_stream(self.device)
         engine.set_stream(self.stream.cuda_stream)
 
+    def close(self):
+        """Detach from the engine: the borrowed torch stream goes back (everything the engine queued on it has finished)
+        and the tensors this adapter holds are dropped; the engine itself stays usable on a stream of its own."""
+        if self.e is not None and getattr(self.e, "_h", None) and self.e._h.value:
+            self.e.release_stream()
+        self._buf = None
+        self.stream = None
+        self.e = None
+
     def set_global_ids(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         self.e._check(self.e._lib.rbpf_set_global_ids(self.e._h, ids.ctypes.data_as(_I32)))
@@ -250,6 +259,14 @@ class ShardedResampler:
     def attach(self, engine_or_shard):
         self.shard = engine_or_shard if hasattr(engine_or_shard, "weights_global") else EngineShard(engine_or_shard, self.device or 0)
         self.shard.set_global_ids(np.arange(self.rank * self.p_local, (self.rank + 1) * self.p_local))
+
+    def close(self):
+        """Drop the device tensors of an unfinished early resample and detach the shard (call before engine.close()
+        and before torch.distributed.destroy_process_group())."""
+        self._early = None
+        if self.shard is not None and hasattr(self.shard, "close"):
+            self.shard.close()
+        self.shard = None
 
     # -- transport helpers ---------------------------------------------------------------------------------------------
     def _all_reduce(self, t):

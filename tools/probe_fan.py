@@ -24,8 +24,8 @@ for mode in ("fan", "window"):
     e.synchronize()
     c = e.counters()
     ms = e.kernel_ms("raycast")
-    print(mode, "raycast ms", np.round(ms, 3).tolist(), "fallbacks", c["window_fallbacks"], "reasons %x" % (0 if sum(c["stamps"]) else c["cells_gathered"]), "slow", c["slow_cells"], "cells", c["ray_cells_visited"], "written", c["cells_written"], flush=True)
-    st = np.array(list(c["stamps"]) + [c["cells_gathered"]], dtype=np.float64)
+    print(mode, "raycast ms", np.round(ms, 3).tolist(), "fallbacks", c["window_fallbacks"], "reasons %x" % c["fallback_reasons"], "slow", c["slow_cells"], "cells", c["ray_cells_visited"], "written", c["cells_written"], flush=True)
+    st = np.array(list(c["stamps"]), dtype=np.float64)
     if st.sum() > 0:
         print("  stamps kcycles/particle-update:", np.round(st / (12 * P) / 1e3, 1).tolist(), "total", round(st.sum() / (12 * P) / 1e3, 1), flush=True)
     e.close()

@@ -24,7 +24,7 @@ for label in ("adj=0 (own map)", "adj=1 (last scan)"):
         r.step()
         if n == 1 and adj != (label.startswith("adj=1")):
             n = 0
-    c = r.e.counters(); st = np.array(list(c["stamps"]) + [c["cells_gathered"]], dtype=np.float64)
+    c = r.e.counters(); st = np.array(list(c["stamps"]), dtype=np.float64)
     ms = r.e.kernel_ms("match")
     print(label, "match ms", ms[-2:], "frames", r.frame)
     for nm, v in zip(names, st):

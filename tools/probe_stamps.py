@@ -13,7 +13,7 @@ r.e.set_profiling(True)
 for _ in range(8):
     r.step()
 c = r.e.counters()
-st = np.array(list(c["stamps"]) + [c["cells_gathered"]], dtype=np.float64)
+st = np.array(list(c["stamps"]), dtype=np.float64)
 names = ["setup", "P0 clear+lut", "P1b rank+oldv", "P2 walk", "P3 replay", "P4 rmw", "end barrier", "P1a flag+clip"]
 print("raycast ms mean", r.e.kernel_ms("raycast").mean())
 for n, v in zip(names, st):
