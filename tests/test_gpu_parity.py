@@ -17,14 +17,20 @@ def eng_mod():
     return engine
 
 
-@pytest.fixture(params=["fan", "window"])
-def map_kernel(request, monkeypatch):
-    """Both map-update kernels: the whole-fan kernel (default where its LDS layout fits) and the 128x128-window
-    kernel (RBPF_MAP_KERNEL=window, read by rbpf_create)."""
-    if request.param == "window":
-        monkeypatch.setenv("RBPF_MAP_KERNEL", "window")
-    else:
+def select_map_kernel(monkeypatch, name):
+    """"ray" = the default (global-index kernel, kernels_mapray.hip); "fan" / "window" through RBPF_MAP_KERNEL, which
+    rbpf_create reads."""
+    if name == "ray":
         monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("RBPF_MAP_KERNEL", name)
+
+
+@pytest.fixture(params=["ray", "fan", "window"])
+def map_kernel(request, monkeypatch):
+    """All three map-update kernels: the global-index kernel (default), the whole-fan kernel of round 1 and the
+    128x128-window kernel both hand their leftovers to."""
+    select_map_kernel(monkeypatch, request.param)
     return request.param
 
 
@@ -137,12 +143,14 @@ def test_map_update_random_particles_vs_oracle(eng_mod, map_kernel):
     e.close()
 
 
+@pytest.mark.parametrize("kernel", ["ray", "fan"])
 @pytest.mark.parametrize("scene", ["near_wall", "one_direction", "tile_corner", "negative_side", "short_rays"])
-def test_map_update_fan_kernel_hard_cases(eng_mod, scene):
+def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
     """Inputs chosen against the whole-fan kernel's layout limits: cells hit by more rays than an 8-bit field may
     hold (the particle is handed to the window kernel), fans that straddle four tiles, the irregular stretch of
     the reference's index formula on the negative side, many flagged cells.  Cell-exact against the oracle."""
     from thesis_amd.datasets import synthetic
+    select_map_kernel(monkeypatch, kernel)
     rng = np.random.Generator(np.random.PCG64(77))
     B = 1081
     ang = synthetic.beam_angles(B)
@@ -178,9 +186,9 @@ def test_map_update_fan_kernel_hard_cases(eng_mod, scene):
     if scene == "one_direction":
         assert c["window_fallbacks"] == P * len(scans)      # the 8-bit guard must have fired for every particle
     if scene == "tile_corner":          # at most a particle or two over the event table; the rest ran in the four-tile window
-        assert c["window_fallbacks"] <= 2, "fallback reasons %x" % c["fallback_reasons"]
-    if scene == "negative_side":        # only the third scan (independent random ranges: too many events) may fall back
-        assert c["window_fallbacks"] <= P, "fallback reasons %x" % c["fallback_reasons"]
+        assert c["window_fallbacks"] <= (0 if kernel == "ray" else 2), "fallback reasons %x" % c["fallback_reasons"]
+    if scene == "negative_side":        # fan kernel: the third scan (independent random ranges: too many events) may fall back
+        assert c["window_fallbacks"] <= (0 if kernel == "ray" else P), "fallback reasons %x" % c["fallback_reasons"]
     e.close()
 
 
@@ -477,7 +485,7 @@ def test_map_update_extreme_beam_counts(eng_mod, B):
     e.close()
 
 
-@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "fan"), (0.1, 180, "window"), (0.05, 721, "window"), (0.025, 181, "fan")])
+@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "ray"), (0.1, 180, "window"), (0.05, 721, "fan"), (0.025, 181, "ray"), (0.1, 180, "ray")])
 def test_closed_loop_population_equals_oracle(eng_mod, monkeypatch, cs, B, kernel):
     """(Cell sizes of configs C1, C2 and C5, both map-update kernels.)  The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
     IMU propagation, Robot.map_update with the engine seam doubled (matcher result and proposal samples injected on both
@@ -485,10 +493,7 @@ def test_closed_loop_population_equals_oracle(eng_mod, monkeypatch, cs, B, kerne
     whenever the spread trigger fires.  Ancestors must agree exactly at every step, state within the north-star
     tolerance, and every particle's map cell for cell at the end."""
     from thesis_amd.datasets import synthetic
-    if kernel == "window":
-        monkeypatch.setenv("RBPF_MAP_KERNEL", "window")
-    else:
-        monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
+    select_map_kernel(monkeypatch, kernel)
     P, K, T = 6, 30, 9
     ang = synthetic.beam_angles(B, np.pi if B < 400 else 1.5 * np.pi)
     rng = np.random.Generator(np.random.PCG64(2024))

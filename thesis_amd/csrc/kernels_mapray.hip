@@ -1,0 +1,689 @@
+// kernels_mapray.hip -- a5: HybridMap.update (hybridmap.py:95-145), counters in GLOBAL cell-index space.
+//
+// One 1024-thread workgroup per particle (16 waves, one workgroup per CU).  Same exact semantics as the other two map
+// kernels (kernels_mapupdate.hip has the ordered-replay argument); what differs:
+//
+//   * The LDS hit counters are indexed by the reference's global integer cell index (hybridmap.py:102,106,123), the
+//     space its Bresenham walks in, not by storage index.  A ray step is then pure arithmetic - no index-map lookups,
+//     no "irregular" path on the negative side of a tile where the reference's float index formula (gridmap.py:93,
+//     SURVEY quirk 3) mis-rounds.  The index map is verified per particle to have the form U(g) = g + C - G(g),
+//     G(g) in {0,1} (it can only round DOWN); the write-back folds it in: storage cell s receives global cell s - C
+//     when that one is not glitched, plus global cell s - C + 1 when that one is.
+//   * Lanes run ALONG a ray: a wave takes one ray and its 64 lanes take 64 consecutive steps, each from the closed
+//     form minor(j) = (fstep * j + 2^21) >> 22 (rbpf_math.h / fix_slope).  Per-ray quantities are wave-uniform (scalar
+//     registers), nothing is carried from step to step, and the adds are fire-and-forget LDS atomics: nothing waits
+//     for a returned value.
+//   * Cells that receive an "occupied" / "nearby" hit (the only ones whose clamped adds do not commute) are not found
+//     by the walk.  The rays through a cell at major distance j, minor offset c are exactly those of the matching
+//     direction class whose fixed-point slope lies in [ceil((c*2^22 - 2^21)/j), ceil(((c+1)*2^22 - 2^21)/j)) and that
+//     are longer than j; rays are bucketed by (class, slope >> 14) once per particle, so each such cell GATHERS its
+//     few rays from two or three buckets, sorts the (beam, rank) events in registers and replays them.  This happens
+//     before anything is written, so every table overflow still hands the particle back untouched.
+//   * A fan larger than the LDS window is processed in strips of storage rows (one launch, any fan size): cell sizes
+//     of 0.025 m and 15 m rays included.  8-bit counters cannot overflow: a bound on the hits of any cell with j >= 16
+//     is checked from the slope buckets first (cells nearer than 16 steps live in a 16-bit block).
+#include "rbpf_mapupdate.h"
+
+namespace rbpf {
+
+#ifdef RBPF_STAMPS
+#define STAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// hand the particle to the window kernel (uniform over the workgroup; nothing has been written to the map yet);
+// reason codes: 1 geometry / index map, 2 counter bound, 3 event tables
+#define GIVE_BACK(reason) do { if (tid == 0) { v.mu_fallback[p] = (reason); atomicAdd(&v.stats[ST_FALLBACK_REASONS], 1ull << (16 * ((reason) - 1))); } return; } while (0)
+
+static const int RB = 1024;                    // threads per particle
+static const int NEAR_R = 16;                  // ray steps j < NEAR_R are counted in the 16-bit block
+static const int NEAR_W = 2 * NEAR_R + 1;      // cells with Chebyshev distance <= NEAR_R from the start cell (one spare ring)
+static const int NBIN = 256;                   // slope buckets per direction class
+static const int RFIX = 22;                    // fixed-point bits of the slope (fix_slope)
+static const int BIN_SHIFT = RFIX - 8;
+static const int RSLOW = 256;                  // flagged cells replayed by the wave-wide exact scan, per particle
+static const int REVT = 16;                    // events a lane sorts in registers
+static const int HIT_BOUND = 63;               // per direction class; two classes can meet in one cell: 126 < 128
+
+struct RayGeom {
+    int fanw, bpad, ncell;
+    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow;
+    int bytes;
+    bool ok;
+};
+
+__host__ __device__ inline int ray_al16(int x) { return (x + 15) & ~15; }
+
+__host__ __device__ inline RayGeom ray_geom(int B, int reach) {
+    RayGeom g;
+    g.fanw = (2 * reach + 8 + 7) & ~7;
+    g.bpad = (B + 3) & ~3;
+    int o = 0;
+    g.o_mini = o;  o += ray_al16(((NEAR_W * NEAR_W + 1) / 2) * 4);
+    g.o_rend = o;  o += ray_al16(g.bpad * 4);
+    g.o_fstep = o; o += ray_al16(g.bpad * 4);
+    g.o_rinfo = o; o += ray_al16(g.bpad);
+    g.o_ux = o;    o += ray_al16(g.fanw * 2);
+    g.o_uy = o;    o += ray_al16(g.fanw * 2);
+    g.o_gxb = o;   o += ray_al16(g.fanw);
+    g.o_gyb = o;   o += ray_al16(g.fanw);
+    g.o_gym = o;   o += ray_al16(g.fanw + 16);
+    g.o_bins = o;  o += 8 * NBIN * 2;                  // 2048 packed 16-bit fill pointers = one 32-bit word per thread
+    g.o_brays = o; o += ray_al16(g.bpad * 2);
+    g.o_oval = o;  o += ray_al16(g.bpad * 2);
+    g.o_slow = o;  o += RSLOW * 2;
+    g.o_cnt = o;
+    const int avail = 160 * 1024 - 1536 - o - 64;      // 1.5 KB for the kernel's static LDS
+    g.ncell = avail > 0 ? avail & ~127 : 0;
+    g.bytes = o + g.ncell;
+    g.ok = g.ncell >= 24576 && B <= 4095 && reach >= NEAR_R + 4 && reach < 1000 && 2LL * reach * reach < (1LL << RFIX);
+    return g;
+}
+
+bool map_update_ray_available(const DevView& v) {
+    const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);
+    return ray_geom(v.B, v.reach).ok && v.dim % 32 == 0 && v.L * v.L <= 49 && v.cc.emp < 0 && sat <= 31 && v.cc.vmax - v.cc.vmin <= 127 &&
+           v.cc.vmin <= 0 && v.cc.vmax >= 0 && v.cc.vmin >= -127 && sat * -v.cc.emp <= 127 && v.cc.thr >= v.cc.vmin && v.cc.thr < v.cc.vmax;
+}
+
+__device__ __forceinline__ uint32_t ray_fix_slope(int dmin, int dmaj) {
+    return dmaj ? (((uint32_t)dmin << RFIX) + (uint32_t)dmaj - 1u) / (uint32_t)dmaj : 0u;
+}
+
+// byte-wise min(field, sat) of four unflagged 7-bit hit counts; flagged bytes (bit 7: the field holds a replayed value)
+// pass through
+__device__ __forceinline__ uint32_t premin4(uint32_t x, uint32_t satb, uint32_t sadd) {
+    const uint32_t n7 = x & 0x7F7F7F7Fu;
+    const uint32_t ge = (n7 + sadd) & 0x80808080u;
+    const uint32_t gem = ge | (ge - (ge >> 7));
+    const uint32_t m = (satb & gem) | (n7 & ~gem);
+    const uint32_t fl = x & 0x80808080u;
+    const uint32_t flm = fl | (fl - (fl >> 7));
+    return (x & flm) | (m & ~flm);
+}
+
+__global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const RayGeom G = ray_geom(v.B, v.reach);
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.o_cnt);     // 8-bit hit fields, [row = global x][col = global y]
+    uint8_t*  const cnt8 = smem + G.o_cnt;
+    uint32_t* const mini = reinterpret_cast<uint32_t*>(smem + G.o_mini);   // [NEAR_W^2] 16-bit fields around the start cell
+    int32_t*  const r_end = reinterpret_cast<int32_t*>(smem + G.o_rend);   // [B] packed end cell relative to the start
+    uint32_t* const r_fstep = reinterpret_cast<uint32_t*>(smem + G.o_fstep); // [B] fixed-point slope
+    uint8_t*  const r_info = smem + G.o_rinfo;                             // [B]
+    uint16_t* const ux = reinterpret_cast<uint16_t*>(smem + G.o_ux);       // U of global column fxl + i
+    uint16_t* const uy = reinterpret_cast<uint16_t*>(smem + G.o_uy);
+    uint8_t*  const gxb = smem + G.o_gxb;                                  // G of global column fxl + i (0 / 1)
+    uint8_t*  const gyb = smem + G.o_gyb;
+    uint8_t*  const gym = smem + G.o_gym;                                  // G of window column lc as a byte mask (0 / 0xFF)
+    uint32_t* const bins32 = reinterpret_cast<uint32_t*>(smem + G.o_bins); // [8 * NBIN] 16-bit counts, then fill pointers
+    uint16_t* const bins16 = reinterpret_cast<uint16_t*>(smem + G.o_bins);
+    uint16_t* const brays = reinterpret_cast<uint16_t*>(smem + G.o_brays); // ray ids ordered by (class, slope bucket)
+    uint8_t*  const oval = smem + G.o_oval;                                // [2 * B] replayed value - vmin of the cell flagged by (beam, e); 0xFF = none / not the owner
+    uint16_t* const slowl = reinterpret_cast<uint16_t*>(smem + G.o_slow);  // [RSLOW] (beam << 1) | e
+
+    __shared__ int s_fb;
+    __shared__ int s_need[49], s_tab[49];
+    __shared__ int s_fan[4];
+    __shared__ int s_wsum[RB / 64];
+    __shared__ int s_nslow, s_written;
+    __shared__ unsigned long long s_cells;
+
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LL = v.L * v.L;
+    const int KW = (v.dim + WIN - 1) / WIN;
+    int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+
+#ifdef RBPF_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#endif
+    // =============================================== setup ===============================================
+    const int pb0 = tid, pb1 = tid + RB;
+    const double pre_x0 = pb0 < v.B ? v.bx[pb0] : 0.0, pre_y0 = pb0 < v.B ? v.by[pb0] : 0.0;
+    const double pre_x1 = pb1 < v.B ? v.bx[pb1] : 0.0, pre_y1 = pb1 < v.B ? v.by[pb1] : 0.0;
+    const int pre_f0 = pb0 < v.B ? v.bflags[pb0] : 0, pre_f1 = pb1 < v.B ? v.bflags[pb1] : 0;
+    const double s_px = v.upd_pose[p], s_py = v.upd_pose[v.P + p];
+    double s_s, s_c;
+    sincos(v.upd_pose[2 * v.P + p], &s_s, &s_c);
+    const int x0 = UNI(trunc_to_int(s_px / v.cs)), y0 = UNI(trunc_to_int(s_py / v.cs));   // hybridmap.py:102
+    {
+        int lx, ly;                                                          // hybridmap.py:98-100
+        bool ok = tile_of_coord(s_px, v.tile_len, v.R, lx) && tile_of_coord(s_py, v.tile_len, v.R, ly);
+        if (ok) ok = tab[(lx + v.R) * v.L + (ly + v.R)] >= 0;
+        const bool in_lut = lut_valid_g(v, x0 - v.reach) && lut_valid_g(v, x0 + v.reach) &&
+                            lut_valid_g(v, y0 - v.reach) && lut_valid_g(v, y0 + v.reach);
+        if (ok && !in_lut) { if (tid == 0) atomicCAS(v.err, 0, RBPF_ERANGE); ok = false; }
+        if (tid == 0) v.mu_fallback[p] = 0;
+        if (!UNI(ok)) return;
+    }
+    // the index map over everything a ray can reach, with a margin of two columns (the sources of a storage cell are its
+    // own global index and the next one)
+    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2, nfx = 2 * v.reach + 5;
+    for (int i = tid; i < G.fanw; i += RB) {
+        const int gxq = fxl + i, gyq = fyl + i;
+        uint32_t ex = lut_valid_g(v, gxq) ? lut_at(v, gxq) : LUT_INVALID, ey = lut_valid_g(v, gyq) ? lut_at(v, gyq) : LUT_INVALID;
+        ux[i] = ex != LUT_INVALID ? (uint16_t)(lut_lat(ex) * v.dim + lut_cidx(ex)) : 0xFFFFu;
+        uy[i] = ey != LUT_INVALID ? (uint16_t)(lut_lat(ey) * v.dim + lut_cidx(ey)) : 0xFFFFu;
+    }
+    if (tid == 0) {
+        s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
+        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0;
+    }
+    for (int i = tid; i < LL; i += RB) { s_need[i] = 0; s_tab[i] = tab[i]; }
+    bins32[tid] = 0;
+    for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += RB) mini[i] = 0;
+    for (int i = tid; i < (2 * G.bpad + 3) / 4; i += RB) reinterpret_cast<uint32_t*>(oval)[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    STAMP(0);
+
+    const int C = v.R * v.dim + v.dim / 2;
+    const int Uxs = UNI(ux[x0 - fxl]), Uys = UNI(uy[y0 - fyl]);
+    const int a0 = Uxs / v.dim, b0 = Uys / v.dim;
+    auto lat_x = [&](int g) { const int U = ux[g - fxl]; return a0 + (U >= (a0 + 1) * v.dim ? 1 : 0) - (U < a0 * v.dim ? 1 : 0); };
+    auto lat_y = [&](int g) { const int U = uy[g - fyl]; return b0 + (U >= (b0 + 1) * v.dim ? 1 : 0) - (U < b0 * v.dim ? 1 : 0); };
+    // direction class and slope bucket of a ray
+    auto ray_key = [&](int ddx, int ddy, uint32_t fstep) {
+        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+        const int cls = (ady > adx ? 4 : 0) | (ddx > 0 ? 2 : 0) | (ddy > 0 ? 1 : 0);
+        const int bin = min((int)(fstep >> BIN_SHIFT), NBIN - 1);
+        return cls * NBIN + bin;
+    };
+    {
+        unsigned long long my_cells = 0;
+        int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
+        for (int b = tid; b < v.B; b += RB) {
+            const double x = b == pb0 ? pre_x0 : b == pb1 ? pre_x1 : v.bx[b], y = b == pb0 ? pre_y0 : b == pb1 ? pre_y1 : v.by[b];
+            const int bf = b == pb0 ? pre_f0 : b == pb1 ? pre_f1 : (int)v.bflags[b];
+            double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
+            double gy = (s_s * x + s_c * y) + s_py;
+            int x1 = trunc_to_int(gx / v.cs), y1 = trunc_to_int(gy / v.cs);        // hybridmap.py:106
+            if (bf & BF_LONG) {                                                    // hybridmap.py:107-113
+                double sc = v.bscale[b];
+                x1 = trunc_to_int((double)x0 + sc * (double)(x1 - x0));
+                y1 = trunc_to_int((double)y0 + sc * (double)(y1 - y0));
+            }
+            int ddx = x1 - x0, ddy = y1 - y0;
+            if (ddx < -v.reach || ddx > v.reach || ddy < -v.reach || ddy > v.reach) {
+                atomicCAS(v.err, 0, RBPF_ERANGE);
+                ddx = 0; ddy = -1; x1 = x0; y1 = y0 - 1;                           // degenerate: no points
+            }
+            r_end[b] = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
+            Ray r = ray_make(x0, y0, x1, y1);
+            int info = 0;
+            uint32_t fstep = 0;
+            if (r.n > 0) {
+                info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
+                my_cells += (unsigned long long)r.n;
+                fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
+                const int a1 = lat_x(x1), b1 = lat_y(y1);
+                if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
+                    int nx, ny;
+                    ray_point(r, r.n - 2, nx, ny);
+                    if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;      // hybridmap.py:141 same tile as the end cell
+                    info |= ((nx - x1 + 1) & 3) << 3;
+                    info |= ((ny - y1 + 1) & 3) << 5;
+                }
+                // tiles entered by this ray (staircase start -> [corner] -> end)
+                s_need[a0 * v.L + b0] = 1;
+                if (a1 != a0 || b1 != b0) {
+                    s_need[a1 * v.L + b1] = 1;
+                    if (a1 != a0 && b1 != b0) {
+                        int gxb_ = r.sx > 0 ? v.gwin[a1 * (KW + 1)] : v.gwin[a0 * (KW + 1)] - 1;
+                        int gyb_ = r.sy > 0 ? v.gwin[b1 * (KW + 1)] : v.gwin[b0 * (KW + 1)] - 1;
+                        int ox = gxb_ - x0; ox = ox < 0 ? -ox : ox;
+                        int oy = gyb_ - y0; oy = oy < 0 ? -oy : oy;
+                        int jx = r.steep ? first_j_minor_ge(r, ox) : ox;
+                        int jy = r.steep ? oy : first_j_minor_ge(r, oy);
+                        if (jx < jy) s_need[a1 * v.L + b0] = 1;
+                        else if (jy < jx) s_need[a0 * v.L + b1] = 1;
+                    }
+                }
+                fstep = ray_fix_slope(r.dmin, r.dmaj);
+                const int key = ray_key(ddx, ddy, fstep);
+                atomicAdd(&bins32[key >> 1], 1u << ((key & 1) * 16));
+            }
+            r_info[b] = (uint8_t)info;
+            r_fstep[b] = fstep;
+        }
+        {
+            const int ws = wave_sum((int)my_cells);
+            fx0 = wave_min(fx0); fx1 = wave_max(fx1); fy0 = wave_min(fy0); fy1 = wave_max(fy1);
+            if (lane == 0) {
+                atomicAdd(&s_cells, (unsigned long long)ws);
+                atomicMin(&s_fan[0], fx0); atomicMax(&s_fan[1], fx1);
+                atomicMin(&s_fan[2], fy0); atomicMax(&s_fan[3], fy1);
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+    // ---- the window: the fan's bounding box in global cell indices; strips of storage rows if it does not fit ----
+    const int bxl = UNI(s_fan[0]), bxh = UNI(s_fan[1]), byl = UNI(s_fan[2]), byh = UNI(s_fan[3]);
+    // the reference's index formula over the fan (one column more on either side): U(g) = g + C - G(g) with G in {0, 1}
+    for (int i = tid; i < G.fanw; i += RB) {
+        const int dxg = (fxl + i + C) - (int)ux[i], dyg = (fyl + i + C) - (int)uy[i];
+        if (fxl + i >= bxl - 1 && fxl + i <= bxh + 1 && (unsigned)dxg > 1u) s_fb = 1;   // also: the LUT ends inside the fan
+        if (fyl + i >= byl - 1 && fyl + i <= byh + 1 && (unsigned)dyg > 1u) s_fb = 1;
+        gxb[i] = (uint8_t)(dxg & 1); gyb[i] = (uint8_t)(dyg & 1);
+    }
+    const int S_lo = UNI(ux[bxl - fxl]), S_hi = UNI(ux[bxh - fxl]);           // storage rows / columns the fan can write
+    const int T_lo = UNI(uy[byl - fyl]), T_hi = UNI(uy[byh - fyl]);
+    const int gy_base = (T_lo - C) & ~3;                                      // window column 0 (C is a multiple of 4)
+    int stride = (T_hi - C + 2 - gy_base + 3) & ~3;                           // columns gy_base .. T_hi - C + 1
+    if (((stride >> 2) & 1) == 0) stride += 4;                                // rows an odd number of banks apart
+    const int rows_cap = G.ncell / stride;                                    // global rows a window can hold
+    BAR_LDS();
+    if (UNI(s_fb) || rows_cap < 8) { GIVE_BACK(1); }
+    if (tid < LL && s_need[tid] && s_tab[tid] < 0) {                          // allocate missing tiles (kept zero-filled)
+        int idx = atomicSub(v.free_top, 1) - 1;
+        if (idx < 0) {
+            atomicAdd(v.free_top, 1);
+            atomicCAS(v.err, 0, RBPF_ENOMEM);
+            s_need[tid] = 0;
+        } else {
+            int t = v.free_stack[idx];
+            s_tab[tid] = t;
+            tab[tid] = t;
+            v.tile_bbox[4 * t + 0] = INT_MAX; v.tile_bbox[4 * t + 1] = -1;
+            v.tile_bbox[4 * t + 2] = INT_MAX; v.tile_bbox[4 * t + 3] = -1;
+        }
+    }
+    for (int lc = tid; lc < stride + 16 && lc < G.fanw + 16; lc += RB) {       // column glitch mask in window coordinates
+        const int i = lc + gy_base - fyl;
+        gym[lc] = (i >= 0 && i < nfx && gyb[i]) ? 0xFFu : 0u;
+    }
+    {   // bucket fill pointers: exclusive prefix sum over the 2048 (class, bucket) counts, two per thread
+        const uint32_t w2 = bins32[tid];
+        const int c0 = (int)(w2 & 0xFFFFu), c1 = (int)(w2 >> 16), pc = c0 + c1;
+        int incl = pc;
+        for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+        if (lane == 63) s_wsum[wave] = incl;
+        BAR_LDS();
+        int wbase = 0;
+        for (int k = 0; k < wave; ++k) wbase += s_wsum[k];
+        const int excl = wbase + incl - pc;
+        bins32[tid] = (uint32_t)excl | ((uint32_t)(excl + c0) << 16);
+    }
+    BAR_LDS();
+    for (int b = tid; b < v.B; b += RB) {
+        if (!(r_info[b] & RI_VALID)) continue;
+        const int32_t e = r_end[b];
+        const int key = ray_key((int)(int16_t)(e & 0xFFFF), (int)(int16_t)((uint32_t)e >> 16), r_fstep[b]);
+        const int sh = (key & 1) * 16;
+        const int pos = (int)((atomicAdd(&bins32[key >> 1], 1u << sh) >> sh) & 0xFFFFu);
+        brays[pos] = (uint16_t)b;
+    }
+    BAR_LDS();
+    // bucket key -> [start, end) in brays (the fill pointers have advanced to the bucket ends)
+    auto bkt_start = [&](int key) { return key ? (int)bins16[key - 1] : 0; };
+    auto bkt_end = [&](int key) { return (int)bins16[key]; };
+    {   // no 8-bit field can overflow: a cell at major distance j >= NEAR_R is hit, per direction class, only by rays
+        // whose slope lies in a window of width 2^RFIX / j + 1 <= 2^18 + 1, i.e. in at most 18 consecutive buckets
+        int mx = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int key = 2 * tid + k, cls = key / NBIN, bin = key % NBIN;
+            const int hi = cls * NBIN + min(bin + 17, NBIN - 1);
+            mx = max(mx, bkt_end(hi) - bkt_start(key));
+        }
+        mx = wave_max(mx);
+        if (lane == 0 && mx > HIT_BOUND) s_fb = 1;
+    }
+    STAMP(2);
+
+    // ---- flagged cells: those that receive an "occupied" or "nearby" hit (hybridmap.py:113,137,139-142) --------------
+    // (beam b, e) flags the storage cell of its end cell (e = 0) or of the cell before it (e = 1).  The owner of a storage
+    // cell is the smallest (b, e) that flags it; it gathers every ray through the cell's global cells from the slope
+    // buckets, sorts the events and replays them on the value the cell has before the scan.
+    const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);        // hits that saturate any cell: 20
+    struct FCell { int sx, sy; int gxs[2], gys[2]; int ngx, ngy; };                // storage cell and its source global cells
+    auto flagged_cell = [&](int b, int e, int info, FCell& f) {
+        int x1, y1;
+        unpack_end(r_end[b], x0, y0, x1, y1);
+        if (e) { x1 += ((info >> 3) & 3) - 1; y1 += ((info >> 5) & 3) - 1; }
+        f.sx = (int)ux[x1 - fxl]; f.sy = (int)uy[y1 - fyl];
+        const int ax = f.sx - C, ay = f.sy - C;                                     // sources: a (if not glitched), a + 1 (if glitched)
+        f.ngx = 0; f.ngy = 0;
+        if (!gxb[ax - fxl]) f.gxs[f.ngx++] = ax;
+        if (gxb[ax + 1 - fxl]) f.gxs[f.ngx++] = ax + 1;
+        if (!gyb[ay - fyl]) f.gys[f.ngy++] = ay;
+        if (gyb[ay + 1 - fyl]) f.gys[f.ngy++] = ay + 1;
+    };
+    auto old_value = [&](const FCell& f) {
+        const int a = f.sx / v.dim, bb = f.sy / v.dim;
+        const int tile = s_need[a * v.L + bb] ? s_tab[a * v.L + bb] : -1;
+        return tile >= 0 ? (int)v.pool[(size_t)tile * v.dim * v.dim + (size_t)(f.sx - a * v.dim) * v.dim + (f.sy - bb * v.dim)] : 0;
+    };
+    for (int b = tid; b < v.B; b += RB) {
+        const int info = r_info[b];
+        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC)) continue;
+        for (int e = 0; e < 2; ++e) {
+            if (e == 1 && !(info & RI_NEAR)) break;
+            FCell f;
+            flagged_cell(b, e, info, f);
+            const int oldv = old_value(f);                                         // in flight during the gather
+            const uint32_t mykey = (uint32_t)(b << 1 | e);
+            // near the sensor most rays cross the cell: the wave-wide scan over all beams does those
+            bool near_cell = false;
+            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
+                const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
+                if (max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy) < NEAR_R) near_cell = true;
+            }
+            if (near_cell) {   // claimed through bit 15 of the first source's 16-bit field: the first claimer owns the cell
+                const int mi = (f.gxs[0] - x0 + NEAR_R) * NEAR_W + (f.gys[0] - y0 + NEAR_R), sh = (mi & 1) * 16;
+                if (!((atomicOr(&mini[mi >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
+                    const int pos = atomicAdd(&s_nslow, 1);
+                    if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
+                }
+                continue;
+            }
+            uint32_t ev[REVT];
+#pragma unroll
+            for (int k = 0; k < REVT; ++k) ev[k] = 0xFFFFFFFFu;
+            int m = 0;
+            bool owner = true;
+            for (int ix = 0; ix < f.ngx && owner; ++ix) for (int iy = 0; iy < f.ngy && owner; ++iy) {
+                const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
+                const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+                for (int steep = 0; steep < 2; ++steep) {
+                    const int j = steep ? ady : adx, c = steep ? adx : ady;
+                    if (c > j) continue;
+                    const int dmaj_s = steep ? ddy : ddx, dmin_s = steep ? ddx : ddy;  // signed offsets along the two axes
+                    int blo = 0, bhi = NBIN - 1;
+                    if (j > 0) {
+                        const float inv = (float)NBIN / (float)j;
+                        blo = max(0, (int)(((float)c - 0.5f) * inv) - 1);
+                        bhi = min(NBIN - 1, (int)(((float)c + 0.5f) * inv) + 1);
+                    }
+                    for (int smin_pos = 0; smin_pos < 2; ++smin_pos) {               // sign class of the minor axis
+                        if (c > 0 && (dmin_s > 0) != (smin_pos == 1)) continue;
+                        const int maj_pos = dmaj_s > 0 ? 1 : 0;
+                        // a ray's signs: sx = dx > 0 ? +1 : -1 (hybridmap.py:282-283); j = 0 only for the start cell, which
+                        // every class reaches
+                        for (int mp = (j > 0 ? maj_pos : 0); mp <= (j > 0 ? maj_pos : 1); ++mp) {
+                            const int sxp = steep ? smin_pos : mp, syp = steep ? mp : smin_pos;
+                            const int cls = steep * 4 + sxp * 2 + syp;
+                            const int st = bkt_start(cls * NBIN + blo), en = bkt_end(cls * NBIN + bhi);
+                            for (int q = st; q < en; ++q) {
+                                const int rb = brays[q];
+                                const int32_t re = r_end[rb];
+                                const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
+                                const int dmaj = steep ? (ey < 0 ? -ey : ey) : (ex < 0 ? -ex : ex);
+                                if (j > dmaj) continue;                              // the ray ends before the cell
+                                if ((int)((r_fstep[rb] * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX) != c) continue;
+                                const int rinfo = r_info[rb];
+                                const int rem = dmaj - j;                            // steps left after this one
+                                const int rank = rem == 0 ? ((rinfo & RI_OCC) ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+                                const bool nearev = rem == 1 && (rinfo & RI_NEAR);
+                                if ((rank == EV_OCC && (uint32_t)(rb << 1) < mykey) || (nearev && (uint32_t)(rb << 1 | 1) < mykey)) { owner = false; break; }
+                                uint32_t key = (uint32_t)(rb << 3 | rank);
+                                for (int two = 0; two < 2; ++two) {
+                                    if (two) { if (!nearev) break; key = (uint32_t)(rb << 3 | EV_NEAR); }
+                                    ++m;
+#pragma unroll
+                                    for (int k = 0; k < REVT; ++k) { const uint32_t lo = min(ev[k], key); key = max(ev[k], key); ev[k] = lo; }
+                                }
+                            }
+                            if (!owner) break;
+                        }
+                        if (!owner) break;
+                    }
+                    if (!owner) break;
+                }
+            }
+            if (!owner) continue;
+            if (m > REVT) {
+                const int pos = atomicAdd(&s_nslow, 1);
+                if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
+                continue;
+            }
+            int val = oldv;
+#pragma unroll
+            for (int k = 0; k < REVT; ++k) if (k < m) val = cell_apply_rank(val, (int)(ev[k] & 7u), v.cc);
+            oval[mykey] = (uint8_t)(val - v.cc.vmin);
+        }
+    }
+    BAR_LDS();
+    if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW ? 3 : 2); }
+    {   // cells near the sensor and cells with more than REVT events: one wave each, exact membership test over all beams
+        const int nslow = UNI(s_nslow);
+        for (int k = wave; k < nslow; k += RB / 64) {
+            const int key = slowl[k], b = key >> 1, e = key & 1;
+            FCell f;
+            flagged_cell(b, e, r_info[b], f);
+            const int val = replay_cell_wave(v, r_info, r_end, x0, y0, f.gxs, f.ngx, f.gys, f.ngy, old_value(f), lane);
+            if (lane == 0) oval[key] = (uint8_t)(val - v.cc.vmin);
+        }
+        if (tid == 0 && nslow) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)nslow);
+    }
+    STAMP(3);
+
+    // =============================================== windows ==============================================
+    const uint32_t satb = (uint32_t)sat * 0x01010101u, sadd = (128u - (uint32_t)sat) * 0x01010101u;
+    int n_win = 0;
+    for (int S0 = S_lo; S0 <= S_hi; S0 += rows_cap - 1, ++n_win) {
+        const int S1 = min(S_hi, S0 + rows_cap - 2);                             // storage rows S0..S1
+        const int gx_base = S0 - C, rows_w = S1 - S0 + 2;                        // global rows gx_base .. gx_base + rows_w - 1
+        BAR_LDS();                                                               // the previous window is done with the counters
+        {
+            uint4* c4 = reinterpret_cast<uint4*>(cnt);
+            const int n16 = (rows_w * stride + 15) >> 4;
+            for (int i = tid; i < n16; i += RB) c4[i] = make_uint4(0, 0, 0, 0);
+        }
+        BAR_LDS();
+        // ---- walk: steps below NEAR_R into the 16-bit block (first window only: it outlives the windows) ----
+        if (n_win == 0) {
+            const int quarter = (v.B + 3) >> 2;                                  // the four rays of a wave instruction point in
+            for (int it = tid; it < quarter * 64; it += RB) {                    // different directions
+                const int qi = it >> 6, l = it & 63;
+                const int b = qi + (l >> 4) * quarter, j = l & 15;
+                if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
+                const int32_t re = r_end[b];
+                const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
+                const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+                const bool steep = aey > aex;
+                const int dmaj = steep ? aey : aex;
+                if (j > dmaj) continue;
+                const int m = (int)((r_fstep[b] * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX);
+                const int sx = ex > 0 ? 1 : -1, sy = ey > 0 ? 1 : -1;
+                const int ddx = steep ? sx * m : sx * j, ddy = steep ? sy * j : sy * m;
+                const int mi = (ddx + NEAR_R) * NEAR_W + (ddy + NEAR_R);
+                atomicAdd(&mini[mi >> 1], 1u << ((mi & 1) * 16));
+            }
+        }
+        BAR_LDS();
+        STAMP(4);
+        // ---- walk: steps from NEAR_R on, one ray per wave at a time, the lanes along the ray ----
+        for (int b = wave; b < v.B; b += RB / 64) {
+            const int info = UNI(r_info[b]);
+            if (!(info & RI_VALID)) continue;
+            const int32_t re = UNI(r_end[b]);
+            const uint32_t fstep = (uint32_t)UNI(r_fstep[b]);
+            const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
+            const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+            const bool steep = aey > aex;
+            const int dmaj = steep ? aey : aex;
+            if (dmaj < NEAR_R) continue;
+            const int sx = ex > 0 ? 1 : -1, sy = ey > 0 ? 1 : -1;
+            // window coordinates of step j: row = rx0 + cjx * j + cmx * m, col = ry0 + cjy * j + cmy * m
+            const int rx0 = x0 - gx_base, ry0 = y0 - gy_base;
+            const int cjx = steep ? 0 : sx, cmx = steep ? sx : 0, cjy = steep ? sy : 0, cmy = steep ? 0 : sy;
+            // rows of the ray inside this window?  (uniform: skip whole rays / blocks)
+            const int xa = rx0, xb = rx0 + ex;
+            if (max(xa, xb) < 0 || min(xa, xb) >= rows_w) continue;
+            for (int jb = NEAR_R; jb <= dmaj; jb += 64) {
+                const int j = jb + lane;
+                const int m = (int)((fstep * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX);
+                const int row = rx0 + cjx * j + cmx * m, col = ry0 + cjy * j + cmy * m;
+                if (j <= dmaj && (unsigned)row < (unsigned)rows_w) {
+                    const int c = row * stride + col;
+                    atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+                }
+            }
+        }
+        BAR_LDS();
+        STAMP(5);
+        // ---- the 16-bit block's counts go into the window (saturated: only min(n, sat) matters for an unflagged cell) ----
+        for (int mi = tid; mi < NEAR_W * NEAR_W; mi += RB) {
+            const int row = x0 + mi / NEAR_W - NEAR_R - gx_base, col = y0 + mi % NEAR_W - NEAR_R - gy_base;
+            if ((unsigned)row >= (unsigned)rows_w || (unsigned)col >= (unsigned)stride) continue;
+            const uint32_t f = (mini[mi >> 1] >> ((mi & 1) * 16)) & 0x7FFFu;       // bit 15: claim flag of a flagged cell
+            if (f) cnt8[row * stride + col] = (uint8_t)min(f, (uint32_t)sat);
+        }
+        BAR_LDS();
+        // ---- the owners put their cell's replayed value into the field of its first source, the other sources vanish ----
+        for (int b = tid; b < v.B; b += RB) {
+            const int info = r_info[b];
+            if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC)) continue;
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t ov = oval[b << 1 | e];
+                if (ov == 0xFFu) continue;
+                FCell f;
+                flagged_cell(b, e, info, f);
+                if (f.sx < S0 || f.sx > S1) continue;
+                for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy)
+                    cnt8[(f.gxs[ix] - gx_base) * stride + (f.gys[iy] - gy_base)] = (ix | iy) ? (uint8_t)0 : (uint8_t)(0x80u | ov);
+            }
+        }
+        BAR_LDS();
+        STAMP(6);
+        // ---- write-back: one read-modify-write per touched 32-cell group of storage cells, tile by tile ----
+        {
+            int my_written = 0;
+            const int eabs = -v.cc.emp;
+            const uint32_t kb1 = (uint32_t)(128 + v.cc.vmin) * 0x01010101u;             // byte-wise: (cell ^ 0x80) - kb1 = cell - vmin
+            const uint32_t oadd = (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u; // bit 7 of (R + oadd) = cell > thr
+            const int gpt = v.dim >> 5;                                                // 32-cell groups per tile row
+            for (int a = S0 / v.dim; a <= S1 / v.dim; ++a)
+            for (int bt = T_lo / v.dim; bt <= T_hi / v.dim; ++bt) {
+                if (a >= v.L || bt >= v.L || !s_need[a * v.L + bt]) continue;          // uniform
+                const int tile = UNI(s_tab[a * v.L + bt]);
+                if (tile < 0) continue;
+                const int sr_lo = max(S0, a * v.dim), sr_hi = min(S1, (a + 1) * v.dim - 1);      // storage rows
+                const int g_lo = max(T_lo >> 5, bt * gpt), g_hi = min(T_hi >> 5, (bt + 1) * gpt - 1);
+                const int ngr = g_hi - g_lo + 1, items = (sr_hi - sr_lo + 1) * ngr;
+                int8_t* __restrict__ tile_base = v.pool + (size_t)tile * v.dim * v.dim;
+                int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
+                for (int it = tid; it < items; it += RB) {
+                    const int rr = it / ngr, gg = it - rr * ngr;
+                    const int srow = sr_lo + rr, Gy = g_lo + gg;
+                    const int ia = srow - C - fxl;                                     // source rows a (if not glitched), a + 1 (if glitched)
+                    const bool va = !gxb[ia], vb = gxb[ia + 1];
+                    if (!va && !vb) continue;                                          // no global row maps here
+                    const int lr = srow - C - gx_base;                                 // window row of source a
+                    const int lc0 = 32 * Gy - C - gy_base;                             // window column of the group's first cell, multiple of 4
+                    uint32_t n[8];
+                    uint32_t any = 0;
+                    {
+                        // glitched columns in the group (its 32 cells and the one after)?
+                        uint32_t gm[9];
+                        uint32_t gany = 0;
+#pragma unroll
+                        for (int w = 0; w < 9; ++w) {
+                            const int lc = lc0 + 4 * w;
+                            gm[w] = (lc >= 0 && lc < stride + 12) ? *reinterpret_cast<const uint32_t*>(gym + lc) : 0u;
+                            gany |= gm[w];
+                        }
+                        const bool both = va && vb;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) n[w] = 0;
+                        for (int src = 0; src < 2; ++src) {
+                            if (src == 0 ? !va : !vb) continue;
+                            const int row = lr + src;
+                            uint32_t x[9];
+#pragma unroll
+                            for (int w = 0; w < 9; ++w) {
+                                const int lc = lc0 + 4 * w;
+                                x[w] = (lc >= 0 && lc < stride) ? cnt[(row * stride + lc) >> 2] : 0u;
+                            }
+                            if (!gany && !both) {
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) n[w] = x[w];
+                            } else {
+#pragma unroll
+                                for (int w = 0; w < 9; ++w) x[w] = premin4(x[w], satb, sadd);
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) {
+                                    const uint32_t keep = x[w] & ~gm[w];
+                                    const uint32_t mv = ((x[w] & gm[w]) >> 8) | ((x[w + 1] & gm[w + 1]) << 24);
+                                    n[w] += keep + mv;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) any |= n[w];
+                    }
+                    if (!any) continue;
+                    const int row_t = srow - a * v.dim, col_t = 32 * Gy - bt * v.dim;
+                    uint32_t* g_ptr = reinterpret_cast<uint32_t*>(tile_base + (size_t)row_t * v.dim + col_t);
+                    const uint4 q0 = reinterpret_cast<const uint4*>(g_ptr)[0], q1 = reinterpret_cast<const uint4*>(g_ptr)[1];
+                    const uint32_t pre[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    uint32_t occ = 0, touched = 0, out[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        const uint32_t Ob = (pre[w] ^ 0x80808080u) - kb1;                   // cells biased to [0, vmax - vmin]
+                        uint32_t R = Ob;
+                        out[w] = pre[w];
+                        if (n[w]) {
+                            const uint32_t nw = n[w], n7 = nw & 0x7F7F7F7Fu;
+                            const uint32_t ge = (n7 + sadd) & 0x80808080u;                  // fields >= sat
+                            const uint32_t gem = ge | (ge - (ge >> 7));
+                            const uint32_t m = (satb & gem) | (n7 & ~gem);                  // min(n, sat)
+                            const uint32_t dec = eabs == 3 ? m + (m << 1) : m * (uint32_t)eabs;
+                            const uint32_t T1 = (Ob | 0x80808080u) - dec;
+                            const uint32_t pos = T1 & 0x80808080u;                          // O - dec >= 0
+                            R = T1 & 0x7F7F7F7Fu & (pos | (pos - (pos >> 7)));
+                            const uint32_t fl = nw & 0x80808080u;
+                            if (fl) {                                                       // replayed cells: the field holds value - vmin
+                                const uint32_t flm = fl | (fl - (fl >> 7));
+                                R = (n7 & flm) | (R & ~flm);
+                            }
+                            out[w] = (R + kb1) ^ 0x80808080u;
+                            const uint32_t nz = ((n7 + 0x7F7F7F7Fu) | nw) & 0x80808080u;    // fields that are not zero
+                            touched |= __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false) << (4 * w);
+                        }
+                        occ |= __builtin_amdgcn_udot4(((R + oadd) & 0x80808080u) >> 7, 0x08040201u, 0u, false) << (4 * w);   // cell > thr
+                    }
+                    reinterpret_cast<uint4*>(g_ptr)[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                    reinterpret_cast<uint4*>(g_ptr)[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                    my_written += __popc(touched);
+                    by0 = min(by0, col_t + __ffs(touched) - 1); by1 = max(by1, col_t + 31 - __clz(touched));
+                    v.occ[((size_t)tile * v.dim + row_t) * v.ow + (col_t >> 5)] = occ;
+                    bx0 = min(bx0, row_t); bx1 = max(bx1, row_t);
+                }
+                bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
+                if (lane == 0 && bx1 >= 0) {                                           // this workgroup is the tile's only writer
+                    atomicMin(&v.tile_bbox[4 * tile + 0], bx0); atomicMax(&v.tile_bbox[4 * tile + 1], bx1);
+                    atomicMin(&v.tile_bbox[4 * tile + 2], by0); atomicMax(&v.tile_bbox[4 * tile + 3], by1);
+                }
+            }
+            const int ww = wave_sum(my_written);
+            if (lane == 0 && ww) atomicAdd(&s_written, ww);
+        }
+        BAR_LDS();
+        STAMP(7);
+    }
+    BAR_LDS();
+    if (tid == 0) {
+        if (s_cells) atomicAdd(&v.stats[ST_RAY_CELLS], s_cells);
+        if (s_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_written);
+        atomicAdd(&v.stats[ST_MAP_WINDOWS], (unsigned long long)n_win);
+#ifdef RBPF_STAMPS
+        for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+#endif
+    }
+}
+
+void launch_map_update_ray(const DevView& v, hipStream_t s) {
+    const RayGeom g = ray_geom(v.B, v.reach);
+    static int lds_attr = 0;
+    if (g.bytes > lds_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(map_update_ray_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, g.bytes);
+        lds_attr = g.bytes;
+    }
+    hipLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, v);
+}
+
+}  // namespace rbpf

@@ -724,8 +724,9 @@ void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    const bool fan = v.mu_mode == 0 && map_update_fan_available(v);
-    if (fan) launch_map_update_fan(v, s);
+    bool fan = false;
+    if (v.mu_mode == 0 && map_update_ray_available(v)) { launch_map_update_ray(v, s); fan = true; }
+    else if (v.mu_mode == 2 && map_update_fan_available(v)) { launch_map_update_fan(v, s); fan = true; }
     hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, d_bad);
 }
 

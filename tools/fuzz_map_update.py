@@ -14,9 +14,9 @@ bad = 0
 for case in range(N):
     cs = float(rng.choice([0.05, 0.05, 0.1, 0.025]))
     B = int(rng.choice([1, 7, 64, 180, 361, 721, 1081, 1081, 1500]))
-    kernel = "window" if rng.random() < 0.4 else "fan"
-    if kernel == "window":
-        os.environ["RBPF_MAP_KERNEL"] = "window"
+    kernel = os.environ.get("FUZZ_KERNEL") or str(rng.choice(["ray", "ray", "ray", "fan", "window"]))
+    if kernel != "ray":
+        os.environ["RBPF_MAP_KERNEL"] = kernel
     else:
         os.environ.pop("RBPF_MAP_KERNEL", None)
     from thesis_amd import engine
@@ -25,7 +25,17 @@ for case in range(N):
     P = 3
     e = engine.ParticleEngine(P, max_beams=B, cell_size=cs, pool_tiles=40)
     maps = [c_oracle.CMap(lib, cs) for _ in range(P)]
-    centre = rng.uniform(-55, 55, size=2) if rng.random() < 0.7 else np.array([rng.choice([-20, 20, 0, 60, -60]), rng.choice([-20, 20, 0])]) + rng.uniform(-0.3, 0.3, 2)
+    # the first tile is centred (0,0) and others exist only once a ray entered them: half of the cases start inside it
+    # (anywhere, negative side included), a fifth at its corners and edges, the rest anywhere (mostly no-ops, hybridmap.py:98-100)
+    pick = rng.random()
+    if pick < 0.5:
+        centre = rng.uniform(-19.5, 19.5, size=2)
+    elif pick < 0.7:
+        centre = np.array([rng.choice([-20, 20, 0]), rng.choice([-20, 20, 0])]) + rng.uniform(-0.4, 0.4, 2)
+    elif pick < 0.85:
+        centre = rng.uniform(-55, 55, size=2)
+    else:
+        centre = np.array([rng.choice([-20, 20, 0, 60, -60]), rng.choice([-20, 20, 0])]) + rng.uniform(-0.3, 0.3, 2)
     ok = True
     for scan in range(int(rng.integers(1, 4))):
         style = rng.random()
@@ -68,5 +78,5 @@ for case in range(N):
     c = e.counters()
     e.close()
     if case % 20 == 0:
-        print("case", case, "ok so far, bad", bad, "cs", cs, "B", B, kernel, "fallbacks", c["window_fallbacks"], flush=True)
+        print("case", case, "ok so far, bad", bad, "cs", cs, "B", B, kernel, "fallbacks", c["window_fallbacks"], "reasons %x" % c["fallback_reasons"], "windows", c["map_windows"], flush=True)
 print("done", N, "cases, mismatching:", bad)
