@@ -18,18 +18,17 @@ def eng_mod():
 
 
 def select_map_kernel(monkeypatch, name):
-    """"ray" = the default (global-index kernel, kernels_mapray.hip); "fan" / "window" through RBPF_MAP_KERNEL, which
-    rbpf_create reads."""
-    if name == "ray":
+    """"auto" = the default chain (whole-fan kernel, then the global-index kernel, then windows); "ray" / "fan" / "window"
+    run only that kernel (and windows for what it gives back), through RBPF_MAP_KERNEL, which rbpf_create reads."""
+    if name == "auto":
         monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
     else:
         monkeypatch.setenv("RBPF_MAP_KERNEL", name)
 
 
-@pytest.fixture(params=["ray", "fan", "window"])
+@pytest.fixture(params=["auto", "ray", "fan", "window"])
 def map_kernel(request, monkeypatch):
-    """All three map-update kernels: the global-index kernel (default), the whole-fan kernel of round 1 and the
-    128x128-window kernel both hand their leftovers to."""
+    """The default chain and each of the three map-update kernels on its own."""
     select_map_kernel(monkeypatch, request.param)
     return request.param
 
@@ -143,7 +142,7 @@ def test_map_update_random_particles_vs_oracle(eng_mod, map_kernel):
     e.close()
 
 
-@pytest.mark.parametrize("kernel", ["ray", "fan"])
+@pytest.mark.parametrize("kernel", ["auto", "ray", "fan"])
 @pytest.mark.parametrize("scene", ["near_wall", "one_direction", "tile_corner", "negative_side", "short_rays"])
 def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
     """Inputs chosen against the whole-fan kernel's layout limits: cells hit by more rays than an 8-bit field may
@@ -186,9 +185,9 @@ def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
     if scene == "one_direction":
         assert c["window_fallbacks"] == P * len(scans)      # the 8-bit guard must have fired for every particle
     if scene == "tile_corner":          # at most a particle or two over the event table; the rest ran in the four-tile window
-        assert c["window_fallbacks"] <= (0 if kernel == "ray" else 2), "fallback reasons %x" % c["fallback_reasons"]
-    if scene == "negative_side":        # fan kernel: the third scan (independent random ranges: too many events) may fall back
-        assert c["window_fallbacks"] <= (0 if kernel == "ray" else P), "fallback reasons %x" % c["fallback_reasons"]
+        assert c["window_fallbacks"] <= (2 if kernel == "fan" else 0), "fallback reasons %x" % c["fallback_reasons"]
+    if scene == "negative_side":        # only the third scan (independent random ranges: cells with dozens of events) may fall back
+        assert c["window_fallbacks"] <= P, "fallback reasons %x" % c["fallback_reasons"]
     e.close()
 
 
@@ -485,7 +484,7 @@ def test_map_update_extreme_beam_counts(eng_mod, B):
     e.close()
 
 
-@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "ray"), (0.1, 180, "window"), (0.05, 721, "fan"), (0.025, 181, "ray"), (0.1, 180, "ray")])
+@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "auto"), (0.1, 180, "window"), (0.05, 721, "fan"), (0.025, 181, "ray"), (0.1, 180, "auto"), (0.05, 361, "ray")])
 def test_closed_loop_population_equals_oracle(eng_mod, monkeypatch, cs, B, kernel):
     """(Cell sizes of configs C1, C2 and C5, both map-update kernels.)  The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
     IMU propagation, Robot.map_update with the engine seam doubled (matcher result and proposal samples injected on both

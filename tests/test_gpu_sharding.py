@@ -116,13 +116,24 @@ class _OneRankDist:
 
 
 def _fault_log(tag):
-    """A fatal signal in a child (also one at interpreter exit) leaves its Python stack in gpurun_out/."""
+    """A fatal signal in a child (also one at interpreter exit) leaves its Python stack in gpurun_out/; a child that
+    ends normally removes the (empty) file from an atexit hook, i.e. after the engines' own teardown hook."""
+    import atexit
     import faulthandler
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        f = open(os.path.join(d, f"child_fault_{tag}_{os.getpid()}.log"), "w")
+        path = os.path.join(d, f"child_fault_{tag}_{os.getpid()}.log")
+        f = open(path, "w")
         faulthandler.enable(f, all_threads=True)
+
+        def tidy():
+            try:
+                if os.path.getsize(path) == 0:
+                    os.remove(path)
+            except OSError:
+                pass
+        atexit.register(tidy)          # registered before thesis_amd.engine is imported: runs after its hook (LIFO)
         return f
     except OSError:
         faulthandler.enable()

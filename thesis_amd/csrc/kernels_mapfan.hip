@@ -302,6 +302,17 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
         if (tid == 0) v.mu_fallback[p] = 0;
         if (!UNI(ok)) return;
     }
+    // Fans that do not fit the window are found only after the whole setup.  When most particles of the previous launch
+    // ended that way (small cells, long rays), this launch leaves its particles to the next kernel at once; every 16th
+    // particle still tries, so that the decision follows the data.
+    {
+        int32_t* const cur = v.mu_hint + 2 * (v.mu_step % 3);
+        const int32_t* const prev = v.mu_hint + 2 * ((v.mu_step + 2) % 3);
+        if (p == 0 && tid < 2) v.mu_hint[2 * ((v.mu_step + 1) % 3) + tid] = 0;
+        const bool skip = prev[0] >= 8 && 2 * prev[1] > prev[0] && (p & 15) != 0;
+        if (UNI(skip)) { GIVE_BACK(1); }
+        if (tid == 0) atomicAdd(&cur[0], 1);
+    }
     // the index map over everything a ray can reach: U of global column fxl + i (fyl + i), i <= 2 * reach
     const int fxl = x0 - v.reach, fyl = y0 - v.reach, nfx = 2 * v.reach + 1, nfy = nfx;
     for (int i = tid; i < G.fanw; i += FB) {
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
     const int stride = (cols_u + 3) & ~3;                                      // this particle's window: rows_u x stride cells
     const int wxc = Uxs - Ux0, wyc = Uys - Uy0al;                              // the start cell in window coordinates
     const int total_irreg = UNI((int)gpx[bxh - fxl] - (int)gpx[bxl - fxl] + (int)gpy[byh - fyl] - (int)gpy[byl - fyl]);
-    if (rows_u * stride > G.ncell || rows_u < 1 || cols_u < 1 || UNI(s_fb)) { GIVE_BACK(1); }
+    if (rows_u * stride > G.ncell || rows_u < 1 || cols_u < 1 || UNI(s_fb)) { if (tid == 0) atomicAdd(&v.mu_hint[2 * (v.mu_step % 3) + 1], 1); GIVE_BACK(1); }
     if (tid == 0) {   // level table: a level's items are padded to whole waves; lane l of a wave takes ray
                       // l * (waves of the level) + wave, so that the lanes of one LDS instruction touch cells far apart
         int cntc[MAXLEV + 1];

@@ -43,12 +43,14 @@ static const int NBIN = 256;                   // slope buckets per direction cl
 static const int RFIX = 22;                    // fixed-point bits of the slope (fix_slope)
 static const int BIN_SHIFT = RFIX - 8;
 static const int RSLOW = 256;                  // flagged cells replayed by the wave-wide exact scan, per particle
-static const int REVT = 16;                    // events a lane sorts in registers
+static const int ECAP = 16;                    // events per flagged cell kept in its list (more: the wave-wide scan)
+static const int RSPEC = 512;                  // flagged cells on an axis or a diagonal through the sensor, per particle
+static const int MAXLEV = 63;                  // whole 16-step chunks per ray (reach < 1000 cells)
 static const int HIT_BOUND = 63;               // per direction class; two classes can meet in one cell: 126 < 128
 
 struct RayGeom {
     int fanw, bpad, ncell;
-    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow;
+    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_scell, o_oldv, o_rcc, o_rdmaj, o_perm, o_rpos, o_pflag;
     int bytes;
     bool ok;
 };
@@ -73,17 +75,31 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
     g.o_brays = o; o += ray_al16(g.bpad * 2);
     g.o_oval = o;  o += ray_al16(g.bpad * 2);
     g.o_slow = o;  o += RSLOW * 2;
+    g.o_scell = o; o += ray_al16(g.bpad * 8);
+    g.o_oldv = o;  o += ray_al16(g.bpad * 2);
+    g.o_rcc = o;   o += ray_al16(g.bpad * 4);
+    g.o_rdmaj = o; o += ray_al16(g.bpad * 2);
+    g.o_perm = o;  o += ray_al16(g.bpad * 2);
+    g.o_rpos = o;  o += ray_al16(g.bpad * 2);
+    g.o_pflag = o; o += ray_al16(g.bpad * 2);
     g.o_cnt = o;
-    const int avail = 160 * 1024 - 1536 - o - 64;      // 1.5 KB for the kernel's static LDS
+    const int avail = 160 * 1024 - 2048 - o - 64;      // 2 KB for the kernel's static LDS
     g.ncell = avail > 0 ? avail & ~127 : 0;
     g.bytes = o + g.ncell;
     g.ok = g.ncell >= 24576 && B <= 4095 && reach >= NEAR_R + 4 && reach < 1000 && 2LL * reach * reach < (1LL << RFIX);
     return g;
 }
 
+// the flagged-cell pass borrows the counter window: 16-bit event counts, ECAP events per pair, the special list
+__host__ __device__ inline bool ray_lists_fit(const RayGeom& g) {
+    const int npair = 2 * g.bpad;
+    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + 4 * g.bpad * 4 <= g.ncell;       // and room for at least 4 candidates per beam
+}
+
 bool map_update_ray_available(const DevView& v) {
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);
-    return ray_geom(v.B, v.reach).ok && v.dim % 32 == 0 && v.L * v.L <= 49 && v.cc.emp < 0 && sat <= 31 && v.cc.vmax - v.cc.vmin <= 127 &&
+    const RayGeom g = ray_geom(v.B, v.reach);
+    return g.ok && ray_lists_fit(g) && v.dim % 32 == 0 && v.L * v.L <= 49 && v.cc.emp < 0 && sat <= 31 && v.cc.vmax - v.cc.vmin <= 127 &&
            v.cc.vmin <= 0 && v.cc.vmax >= 0 && v.cc.vmin >= -127 && sat * -v.cc.emp <= 127 && v.cc.thr >= v.cc.vmin && v.cc.thr < v.cc.vmax;
 }
 
@@ -103,7 +119,8 @@ __device__ __forceinline__ uint32_t premin4(uint32_t x, uint32_t satb, uint32_t 
     return (x & flm) | (m & ~flm);
 }
 
-__global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
+__global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int32_t* __restrict__ only) {
+    if (only && !only[blockIdx.x]) return;                                 // the kernel that ran first did this particle
     extern __shared__ __align__(16) unsigned char smem[];
     const RayGeom G = ray_geom(v.B, v.reach);
     uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.o_cnt);     // 8-bit hit fields, [row = global x][col = global y]
@@ -122,12 +139,20 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
     uint16_t* const brays = reinterpret_cast<uint16_t*>(smem + G.o_brays); // ray ids ordered by (class, slope bucket)
     uint8_t*  const oval = smem + G.o_oval;                                // [2 * B] replayed value - vmin of the cell flagged by (beam, e); 0xFF = none / not the owner
     uint16_t* const slowl = reinterpret_cast<uint16_t*>(smem + G.o_slow);  // [RSLOW] (beam << 1) | e
+    uint32_t* const scell = reinterpret_cast<uint32_t*>(smem + G.o_scell); // [2 * B] storage cell (U_x << 16 | U_y) flagged by (beam, e), ~0 = none
+    uint8_t*  const oldv8 = smem + G.o_oldv;                               // [2 * B] its value before the scan
+    uint32_t* const r_cc = reinterpret_cast<uint32_t*>(smem + G.o_rcc);    // [B] window-address steps of the ray: per major step | per minor step << 16
+    uint16_t* const r_dmaj = reinterpret_cast<uint16_t*>(smem + G.o_rdmaj); // [B] last step of the ray
+    uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole 16-step chunks
+    uint16_t* const rpos = reinterpret_cast<uint16_t*>(smem + G.o_rpos);   // [B] position of the ray in brays
+    uint8_t*  const pflag = smem + G.o_pflag;                              // [2 * B] 0 = pair not in play, 1 = gathered, 2 = other classes too
 
     __shared__ int s_fb;
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];
     __shared__ int s_wsum[RB / 64];
-    __shared__ int s_nslow, s_written;
+    __shared__ int s_nslow, s_written, s_nspec, s_ncand;
+    __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,10 +193,11 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
     }
     if (tid == 0) {
         s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
-        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0;
+        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_ncand = 0;
     }
     for (int i = tid; i < LL; i += RB) { s_need[i] = 0; s_tab[i] = tab[i]; }
     bins32[tid] = 0;
+    if (tid <= MAXLEV) s_lcnt[tid] = 0;
     for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += RB) mini[i] = 0;
     for (int i = tid; i < (2 * G.bpad + 3) / 4; i += RB) reinterpret_cast<uint32_t*>(oval)[i] = 0xFFFFFFFFu;
     __syncthreads();
@@ -212,15 +238,17 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
             Ray r = ray_make(x0, y0, x1, y1);
             int info = 0;
             uint32_t fstep = 0;
+            uint32_t sc0 = 0xFFFFFFFFu, sc1 = 0xFFFFFFFFu;
             if (r.n > 0) {
                 info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
+                if (info & RI_OCC) sc0 = ((uint32_t)ux[x1 - fxl] << 16) | (uint32_t)uy[y1 - fyl];
                 my_cells += (unsigned long long)r.n;
                 fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
                 const int a1 = lat_x(x1), b1 = lat_y(y1);
                 if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
                     int nx, ny;
                     ray_point(r, r.n - 2, nx, ny);
-                    if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;      // hybridmap.py:141 same tile as the end cell
+                    if (lat_x(nx) == a1 && lat_y(ny) == b1) { info |= RI_NEAR; sc1 = ((uint32_t)ux[nx - fxl] << 16) | (uint32_t)uy[ny - fyl]; }   // hybridmap.py:141 same tile as the end cell
                     info |= ((nx - x1 + 1) & 3) << 3;
                     info |= ((ny - y1 + 1) & 3) << 5;
                 }
@@ -242,9 +270,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
                 fstep = ray_fix_slope(r.dmin, r.dmaj);
                 const int key = ray_key(ddx, ddy, fstep);
                 atomicAdd(&bins32[key >> 1], 1u << ((key & 1) * 16));
+                const int nfull = (r.dmaj + 1) / NEAR_R - 1;                         // whole chunks after level 0
+                if (nfull >= 1) atomicAdd(&s_lcnt[min(nfull, MAXLEV)], 1);
             }
+            r_dmaj[b] = (uint16_t)(r.n > 0 ? r.dmaj : 0);
             r_info[b] = (uint8_t)info;
             r_fstep[b] = fstep;
+            scell[2 * b] = sc0; scell[2 * b + 1] = sc1;
         }
         {
             const int ws = wave_sum((int)my_cells);
@@ -257,7 +289,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
         }
     }
     __syncthreads();
-    STAMP(1);
+    STAMP(0);
     // ---- the window: the fan's bounding box in global cell indices; strips of storage rows if it does not fit ----
     const int bxl = UNI(s_fan[0]), bxh = UNI(s_fan[1]), byl = UNI(s_fan[2]), byh = UNI(s_fan[3]);
     // the reference's index formula over the fan (one column more on either side): U(g) = g + C - G(g) with G in {0, 1}
@@ -289,6 +321,21 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
             v.tile_bbox[4 * t + 2] = INT_MAX; v.tile_bbox[4 * t + 3] = -1;
         }
     }
+    if (wave == 0) {   // levels: N_k = rays with at least k whole chunks (suffix sums over the wave: MAXLEV = 63)
+        const int k = lane;                                                    // lane 0 is unused (level 0 = the 16-bit block)
+        const int ck = k >= 1 ? s_lcnt[k] : 0;
+        int suf = ck;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(suf, o, 64); if (lane + o < 64) suf += t; }
+        // suf = N_k; rays with more chunks come first in perm
+        const int nwk = k >= 1 ? (suf + 63) >> 6 : 0;
+        int pre = nwk;                                                         // inclusive prefix of the levels' wave counts
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
+        const unsigned long long live = __ballot(k >= 1 && suf > 0);
+        const int nlev = live ? 63 - __clzll((long long)live) : 0;
+        if (k >= 1) { s_lfill[k] = suf - ck; s_nk[k] = suf; s_lp[k] = pre - nwk; }
+        if (k == 63) s_lp[64] = pre;
+        if (k == 0) { s_nlev = nlev; s_nk[MAXLEV + 1] = 0; }
+    }
     for (int lc = tid; lc < stride + 16 && lc < G.fanw + 16; lc += RB) {       // column glitch mask in window coordinates
         const int i = lc + gy_base - fyl;
         gym[lc] = (i >= 0 && i < nfx && gyb[i]) ? 0xFFu : 0u;
@@ -313,6 +360,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
         const int sh = (key & 1) * 16;
         const int pos = (int)((atomicAdd(&bins32[key >> 1], 1u << sh) >> sh) & 0xFFFFu);
         brays[pos] = (uint16_t)b;
+        const int ex = (int)(int16_t)(e & 0xFFFF), ey = (int)(int16_t)((uint32_t)e >> 16);
+        const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+        const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
+        const int cj = aey > aex ? sy1 : sxs, cm = aey > aex ? sxs : sy1;
+        r_cc[b] = ((uint32_t)cj & 0xFFFFu) | ((uint32_t)cm << 16);
+        const int nfull = ((int)r_dmaj[b] + 1) / NEAR_R - 1;
+        if (nfull >= 1) perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
     }
     BAR_LDS();
     // bucket key -> [start, end) in brays (the fill pointers have advanced to the bucket ends)
@@ -330,19 +384,24 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
         mx = wave_max(mx);
         if (lane == 0 && mx > HIT_BOUND) s_fb = 1;
     }
-    STAMP(2);
+    STAMP(1);
 
     // ---- flagged cells: those that receive an "occupied" or "nearby" hit (hybridmap.py:113,137,139-142) --------------
-    // (beam b, e) flags the storage cell of its end cell (e = 0) or of the cell before it (e = 1).  The owner of a storage
-    // cell is the smallest (b, e) that flags it; it gathers every ray through the cell's global cells from the slope
-    // buckets, sorts the events and replays them on the value the cell has before the scan.
+    // Pair (beam b, e) flags the storage cell of b's end cell (e = 0) or of the cell before it (e = 1); the smallest pair
+    // that flags a storage cell owns it.  The rays of a direction class are sorted by slope, and the rays through a cell at
+    // major distance j are exactly those with minor(j) = c: a contiguous run in that order around b itself.  Every pair
+    // scans its neighbours in its own class (a handful), tests them exactly against the cell's global source cells and
+    // keeps the (beam, rank) events; cells that rays of another class can reach too (on an axis or a diagonal through the
+    // sensor) are finished by a second, dense pass with one lane per (cell, class).  The counter window is not in use yet:
+    // the event lists live there.
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);        // hits that saturate any cell: 20
+    const int npair = 2 * G.bpad;
+    uint32_t* const evn32 = cnt;                                                   // [npair] 16-bit event counts
+    uint16_t* const evl = reinterpret_cast<uint16_t*>(cnt + npair / 2);            // [npair][ECAP] (beam << 3) | rank
+    uint16_t* const spl = evl + npair * ECAP;                                      // [RSPEC] pairs that need the other classes
     struct FCell { int sx, sy; int gxs[2], gys[2]; int ngx, ngy; };                // storage cell and its source global cells
-    auto flagged_cell = [&](int b, int e, int info, FCell& f) {
-        int x1, y1;
-        unpack_end(r_end[b], x0, y0, x1, y1);
-        if (e) { x1 += ((info >> 3) & 3) - 1; y1 += ((info >> 5) & 3) - 1; }
-        f.sx = (int)ux[x1 - fxl]; f.sy = (int)uy[y1 - fyl];
+    auto cell_sources = [&](uint32_t sc, FCell& f) {
+        f.sx = (int)(sc >> 16); f.sy = (int)(sc & 0xFFFFu);
         const int ax = f.sx - C, ay = f.sy - C;                                     // sources: a (if not glitched), a + 1 (if glitched)
         f.ngx = 0; f.ngy = 0;
         if (!gxb[ax - fxl]) f.gxs[f.ngx++] = ax;
@@ -355,22 +414,83 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
         const int tile = s_need[a * v.L + bb] ? s_tab[a * v.L + bb] : -1;
         return tile >= 0 ? (int)v.pool[(size_t)tile * v.dim * v.dim + (size_t)(f.sx - a * v.dim) * v.dim + (f.sy - bb * v.dim)] : 0;
     };
+    // does ray rb pass through the global cell at offset (ddx, ddy) from the start cell?  If so: the event's rank and
+    // whether the NEARBY event follows (hybridmap.py:139-142).  Exact: the closed form of the reference's Bresenham.
+    struct RayP { int ex, ey, dmaj, steep, smaj, smin, info; uint32_t fs; };
+    auto load_ray = [&](int rb, RayP& r) {
+        const int32_t re = r_end[rb];
+        r.ex = (int)(int16_t)(re & 0xFFFF); r.ey = (int)(int16_t)((uint32_t)re >> 16);
+        const int aex = r.ex < 0 ? -r.ex : r.ex, aey = r.ey < 0 ? -r.ey : r.ey;
+        r.steep = aey > aex; r.dmaj = r.steep ? aey : aex;
+        const int sx = r.ex > 0 ? 1 : -1, sy = r.ey > 0 ? 1 : -1;                    // hybridmap.py:282-283
+        r.smaj = r.steep ? sy : sx; r.smin = r.steep ? sx : sy;
+        r.fs = r_fstep[rb]; r.info = r_info[rb];
+    };
+    auto ray_hits = [&](const RayP& r, int ddx, int ddy, int& rank, bool& nearev) {
+        const int j = (r.steep ? ddy : ddx) * r.smaj, c = (r.steep ? ddx : ddy) * r.smin;   // both must be >= 0
+        if (j < 0 || c < 0 || j > r.dmaj) return false;
+        if ((int)((r.fs * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX) != c) return false;
+        const int rem = r.dmaj - j;                                                  // steps left after this one
+        rank = rem == 0 ? ((r.info & RI_OCC) ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+        nearev = rem == 1 && (r.info & RI_NEAR);
+        return true;
+    };
+    {   // order the rays of every bucket by slope (ties by beam): the class is then sorted as a whole; rpos = inverse
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int key = 2 * tid + k, st = bkt_start(key), en = bkt_end(key);
+            if (en - st > 12) s_fb = 1;                                             // (a regular scan has one or two rays per bucket)
+            else for (int i = st + 1; i < en; ++i) {
+                const int rb = brays[i];
+                const uint32_t fbase = (uint32_t)(key % NBIN) << BIN_SHIFT;          // slopes of a bucket differ in their low 14 (15 in the last) bits
+                const uint32_t kf = ((r_fstep[rb] - fbase) << 12) | (uint32_t)rb;
+                int q = i - 1;
+                while (q >= st) {
+                    const int ro = brays[q];
+                    if ((((r_fstep[ro] - fbase) << 12) | (uint32_t)ro) <= kf) break;
+                    brays[q + 1] = (uint16_t)ro; --q;
+                }
+                brays[q + 1] = (uint16_t)rb;
+            }
+        }
+        for (int i = tid; i < npair / 2; i += RB) evn32[i] = 0;
+        for (int i = tid; i < npair / 4; i += RB) reinterpret_cast<uint32_t*>(pflag)[i] = 0;
+    }
+    BAR_LDS();
+    for (int q = tid; q < UNI(bkt_end(8 * NBIN - 1)); q += RB) rpos[brays[q]] = (uint16_t)q;
+    BAR_LDS();
+    STAMP(2);
+    // ---- pass 1: every pair finds the run of its own class that can reach its cell and lists it as candidates ----
+    uint32_t* const cand = reinterpret_cast<uint32_t*>(spl + RSPEC);               // [ncand_cap] pair << 16 | position in brays
+    const int ncand_cap = (G.ncell - (npair * 2 + npair * ECAP * 2 + RSPEC * 2)) / 4;
     for (int b = tid; b < v.B; b += RB) {
-        const int info = r_info[b];
-        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC)) continue;
         for (int e = 0; e < 2; ++e) {
-            if (e == 1 && !(info & RI_NEAR)) break;
+            const uint32_t sc = scell[2 * b + e];
+            if (sc == 0xFFFFFFFFu) break;
+            // a smaller pair on the same storage cell: this one cannot be the owner (the rest of the duplicates show up in pass 3)
+            bool dup = e == 1 && scell[2 * b] == sc;
+            if (b >= 1) dup = dup || scell[2 * b - 2] == sc || scell[2 * b - 1] == sc;
+            if (b >= 2) dup = dup || scell[2 * b - 4] == sc;
+            if (dup) continue;
             FCell f;
-            flagged_cell(b, e, info, f);
-            const int oldv = old_value(f);                                         // in flight during the gather
-            const uint32_t mykey = (uint32_t)(b << 1 | e);
-            // near the sensor most rays cross the cell: the wave-wide scan over all beams does those
-            bool near_cell = false;
+            cell_sources(sc, f);
+            const int oldv = old_value(f);                                         // in flight during the search
+            const int mykey = b << 1 | e;
+            RayP me;
+            load_ray(b, me);
+            // the cell in the frame of b's class: major distance j, minor offset c of every source
+            const int jg = me.dmaj - e;                                            // b itself crosses the cell at step jg
+            int lo = INT_MAX, hi = -1;                                             // window on minor(jg) of a ray that can reach a source
+            bool near_cell = false, special = false;
             for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
                 const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
                 if (max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy) < NEAR_R) near_cell = true;
+                const int js = (me.steep ? ddy : ddx) * me.smaj, cs_ = (me.steep ? ddx : ddy) * me.smin;
+                if (cs_ <= 0 || cs_ >= js) special = true;                           // an axis or a diagonal through the sensor: other classes reach it
+                const int w = js != jg ? 1 : 0;
+                lo = min(lo, cs_ - w); hi = max(hi, cs_ + w);
             }
-            if (near_cell) {   // claimed through bit 15 of the first source's 16-bit field: the first claimer owns the cell
+            if (near_cell) {   // most rays cross it: the wave-wide scan over all beams; claimed through bit 15 of the first source's 16-bit field
                 const int mi = (f.gxs[0] - x0 + NEAR_R) * NEAR_W + (f.gys[0] - y0 + NEAR_R), sh = (mi & 1) * 16;
                 if (!((atomicOr(&mini[mi >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
                     const int pos = atomicAdd(&s_nslow, 1);
@@ -378,80 +498,118 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
                 }
                 continue;
             }
-            uint32_t ev[REVT];
-#pragma unroll
-            for (int k = 0; k < REVT; ++k) ev[k] = 0xFFFFFFFFu;
-            int m = 0;
-            bool owner = true;
-            for (int ix = 0; ix < f.ngx && owner; ++ix) for (int iy = 0; iy < f.ngy && owner; ++iy) {
-                const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
-                const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
-                for (int steep = 0; steep < 2; ++steep) {
-                    const int j = steep ? ady : adx, c = steep ? adx : ady;
-                    if (c > j) continue;
-                    const int dmaj_s = steep ? ddy : ddx, dmin_s = steep ? ddx : ddy;  // signed offsets along the two axes
-                    int blo = 0, bhi = NBIN - 1;
-                    if (j > 0) {
-                        const float inv = (float)NBIN / (float)j;
-                        blo = max(0, (int)(((float)c - 0.5f) * inv) - 1);
-                        bhi = min(NBIN - 1, (int)(((float)c + 0.5f) * inv) + 1);
-                    }
-                    for (int smin_pos = 0; smin_pos < 2; ++smin_pos) {               // sign class of the minor axis
-                        if (c > 0 && (dmin_s > 0) != (smin_pos == 1)) continue;
-                        const int maj_pos = dmaj_s > 0 ? 1 : 0;
-                        // a ray's signs: sx = dx > 0 ? +1 : -1 (hybridmap.py:282-283); j = 0 only for the start cell, which
-                        // every class reaches
-                        for (int mp = (j > 0 ? maj_pos : 0); mp <= (j > 0 ? maj_pos : 1); ++mp) {
-                            const int sxp = steep ? smin_pos : mp, syp = steep ? mp : smin_pos;
-                            const int cls = steep * 4 + sxp * 2 + syp;
-                            const int st = bkt_start(cls * NBIN + blo), en = bkt_end(cls * NBIN + bhi);
-                            for (int q = st; q < en; ++q) {
-                                const int rb = brays[q];
-                                const int32_t re = r_end[rb];
-                                const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
-                                const int dmaj = steep ? (ey < 0 ? -ey : ey) : (ex < 0 ? -ex : ex);
-                                if (j > dmaj) continue;                              // the ray ends before the cell
-                                if ((int)((r_fstep[rb] * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX) != c) continue;
-                                const int rinfo = r_info[rb];
-                                const int rem = dmaj - j;                            // steps left after this one
-                                const int rank = rem == 0 ? ((rinfo & RI_OCC) ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
-                                const bool nearev = rem == 1 && (rinfo & RI_NEAR);
-                                if ((rank == EV_OCC && (uint32_t)(rb << 1) < mykey) || (nearev && (uint32_t)(rb << 1 | 1) < mykey)) { owner = false; break; }
-                                uint32_t key = (uint32_t)(rb << 3 | rank);
-                                for (int two = 0; two < 2; ++two) {
-                                    if (two) { if (!nearev) break; key = (uint32_t)(rb << 3 | EV_NEAR); }
-                                    ++m;
-#pragma unroll
-                                    for (int k = 0; k < REVT; ++k) { const uint32_t lo = min(ev[k], key); key = max(ev[k], key); ev[k] = lo; }
-                                }
-                            }
-                            if (!owner) break;
-                        }
-                        if (!owner) break;
-                    }
-                    if (!owner) break;
-                }
+            const int cls = me.steep * 4 + (me.ex > 0 ? 2 : 0) + (me.ey > 0 ? 1 : 0);
+            const int cst = bkt_start(cls * NBIN), cen = bkt_end(cls * NBIN + NBIN - 1);
+            // the class is sorted by slope, so minor(jg) never decreases along it: the run is contiguous around b
+            const int q0 = rpos[b];
+            int ql = q0, qr = q0 + 1;
+            while (ql > cst && (int)((r_fstep[brays[ql - 1]] * (uint32_t)jg + (1u << (RFIX - 1))) >> RFIX) >= lo) --ql;
+            while (qr < cen && (int)((r_fstep[brays[qr]] * (uint32_t)jg + (1u << (RFIX - 1))) >> RFIX) <= hi) ++qr;
+            const int n = qr - ql;
+            const int off = atomicAdd(&s_ncand, n);
+            if (off + n <= ncand_cap) { for (int t = 0; t < n; ++t) cand[off + t] = ((uint32_t)mykey << 16) | (uint32_t)(ql + t); }
+            else s_fb = 1;
+            oldv8[mykey] = (uint8_t)oldv;
+            pflag[mykey] = special ? 2 : 1;
+            if (special) {
+                const int pos = atomicAdd(&s_nspec, 1);
+                if (pos < RSPEC) spl[pos] = (uint16_t)mykey; else s_fb = 1;
             }
-            if (!owner) continue;
-            if (m > REVT) {
-                const int pos = atomicAdd(&s_nslow, 1);
-                if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
-                continue;
-            }
-            int val = oldv;
-#pragma unroll
-            for (int k = 0; k < REVT; ++k) if (k < m) val = cell_apply_rank(val, (int)(ev[k] & 7u), v.cc);
-            oval[mykey] = (uint8_t)(val - v.cc.vmin);
         }
     }
     BAR_LDS();
-    if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW ? 3 : 2); }
-    {   // cells near the sensor and cells with more than REVT events: one wave each, exact membership test over all beams
+    STAMP(3);
+    // ---- pass 2a: one lane per candidate ----
+    {
+        const int ncand = UNI(min(s_ncand, ncand_cap));
+        for (int t = tid; t < ncand; t += RB) {
+            const uint32_t cd = cand[t];
+            const int pair = (int)(cd >> 16), rb = brays[cd & 0xFFFFu];
+            RayP r;
+            load_ray(rb, r);
+            FCell f;
+            cell_sources(scell[pair], f);
+            const int psh = (pair & 1) * 16;
+            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
+                int rank; bool nearev;
+                if (!ray_hits(r, f.gxs[ix] - x0, f.gys[iy] - y0, rank, nearev)) continue;
+                int pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
+                if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | rank);
+                if (nearev) {
+                    pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
+                    if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | EV_NEAR);
+                }
+            }
+        }
+    }
+    // ---- pass 2b: cells other classes reach too; one lane per (cell, other class) ----
+    {
+        const int nspec = UNI(min(s_nspec, RSPEC));
+        for (int it = tid; it < nspec * 8; it += RB) {
+            const int pair = spl[it >> 3], cls = it & 7, b = pair >> 1;
+            RayP me;
+            load_ray(b, me);
+            if (cls == me.steep * 4 + (me.ex > 0 ? 2 : 0) + (me.ey > 0 ? 1 : 0)) continue;      // done in pass 1
+            FCell f;
+            cell_sources(scell[pair], f);
+            // slope buckets of this class that can hold a ray through one of the sources
+            const int steep = cls >> 2, smaj = steep ? ((cls & 1) ? 1 : -1) : ((cls & 2) ? 1 : -1), smin = steep ? ((cls & 2) ? 1 : -1) : ((cls & 1) ? 1 : -1);
+            int blo = NBIN, bhi = -1;
+            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
+                const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
+                const int j = (steep ? ddy : ddx) * smaj, c = (steep ? ddx : ddy) * smin;
+                if (j <= 0 || c < 0 || c > j) continue;
+                const float inv = (float)NBIN / (float)j;
+                blo = min(blo, max(0, (int)(((float)c - 0.5f) * inv) - 1));
+                bhi = max(bhi, min(NBIN - 1, (int)(((float)c + 0.5f) * inv) + 1));
+            }
+            if (bhi < blo) continue;
+            const int psh = (pair & 1) * 16;
+            for (int q = bkt_start(cls * NBIN + blo); q < bkt_end(cls * NBIN + bhi); ++q) {
+                const int rb = brays[q];
+                RayP r;
+                load_ray(rb, r);
+                for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
+                    int rank; bool nearev;
+                    if (!ray_hits(r, f.gxs[ix] - x0, f.gys[iy] - y0, rank, nearev)) continue;
+                    int pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
+                    if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | rank);
+                    if (nearev) {
+                        pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
+                        if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | EV_NEAR);
+                    }
+                }
+            }
+        }
+    }
+    BAR_LDS();
+    // ---- pass 3: every pair with events checks that it owns its cell, sorts the events and replays them ----
+    for (int pair = tid; pair < 2 * v.B; pair += RB) {
+        if (!pflag[pair]) continue;
+        const int m = (int)((evn32[pair >> 1] >> ((pair & 1) * 16)) & 0xFFFFu);
+        if (m > ECAP) {                                                          // (duplicates may both land here: same value twice)
+            const int pos = atomicAdd(&s_nslow, 1);
+            if (pos < RSLOW) slowl[pos] = (uint16_t)pair; else s_fb = 1;
+            continue;
+        }
+        const uint16_t* evp = evl + pair * ECAP;
+        bool owner = true;
+        for (int k = 0; k < m; ++k) {
+            const int key = evp[k], rank = key & 7, rp = (key >> 3) << 1;
+            if ((rank == EV_OCC && rp < pair) || (rank == EV_NEAR && (rp | 1) < pair)) owner = false;
+        }
+        if (!owner) continue;
+        const int val = m <= 8 ? replay_sorted<8>(evp, m, (int)(int8_t)oldv8[pair], v.cc) : replay_sorted<ECAP>(evp, m, (int)(int8_t)oldv8[pair], v.cc);
+        oval[pair] = (uint8_t)(val - v.cc.vmin);
+    }
+    BAR_LDS();
+    if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW || UNI(s_nspec) > RSPEC || UNI(s_ncand) > ncand_cap ? 3 : 2); }
+    {   // cells near the sensor and cells with more than ECAP events: one wave each, exact membership test over all beams
         const int nslow = UNI(s_nslow);
         for (int k = wave; k < nslow; k += RB / 64) {
-            const int key = slowl[k], b = key >> 1, e = key & 1;
+            const int key = slowl[k];
             FCell f;
-            flagged_cell(b, e, r_info[b], f);
+            cell_sources(scell[key], f);
             const int val = replay_cell_wave(v, r_info, r_end, x0, y0, f.gxs, f.ngx, f.gys, f.ngy, old_value(f), lane);
             if (lane == 0) oval[key] = (uint8_t)(val - v.cc.vmin);
         }
@@ -472,53 +630,94 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
             for (int i = tid; i < n16; i += RB) c4[i] = make_uint4(0, 0, 0, 0);
         }
         BAR_LDS();
-        // ---- walk: steps below NEAR_R into the 16-bit block (first window only: it outlives the windows) ----
-        if (n_win == 0) {
-            const int quarter = (v.B + 3) >> 2;                                  // the four rays of a wave instruction point in
-            for (int it = tid; it < quarter * 64; it += RB) {                    // different directions
-                const int qi = it >> 6, l = it & 63;
-                const int b = qi + (l >> 4) * quarter, j = l & 15;
-                if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
-                const int32_t re = r_end[b];
-                const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
-                const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
-                const bool steep = aey > aex;
-                const int dmaj = steep ? aey : aex;
-                if (j > dmaj) continue;
-                const int m = (int)((r_fstep[b] * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX);
-                const int sx = ex > 0 ? 1 : -1, sy = ey > 0 ? 1 : -1;
-                const int ddx = steep ? sx * m : sx * j, ddy = steep ? sy * j : sy * m;
-                const int mi = (ddx + NEAR_R) * NEAR_W + (ddy + NEAR_R);
-                atomicAdd(&mini[mi >> 1], 1u << ((mi & 1) * 16));
-            }
-        }
-        BAR_LDS();
         STAMP(4);
-        // ---- walk: steps from NEAR_R on, one ray per wave at a time, the lanes along the ray ----
-        for (int b = wave; b < v.B; b += RB / 64) {
-            const int info = UNI(r_info[b]);
-            if (!(info & RI_VALID)) continue;
-            const int32_t re = UNI(r_end[b]);
-            const uint32_t fstep = (uint32_t)UNI(r_fstep[b]);
-            const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
-            const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
-            const bool steep = aey > aex;
-            const int dmaj = steep ? aey : aex;
-            if (dmaj < NEAR_R) continue;
-            const int sx = ex > 0 ? 1 : -1, sy = ey > 0 ? 1 : -1;
-            // window coordinates of step j: row = rx0 + cjx * j + cmx * m, col = ry0 + cjy * j + cmy * m
+        // ---- walk: lanes are rays, a work item is one 16-step chunk of 64 rays ----
+        // Level k = steps 16k .. 16k + 15.  The rays that own a whole k-th chunk are perm[0 .. N_k) (rays ordered by falling
+        // chunk count), so every lane of an item runs all 16 steps: no predicates.  Lane l of the w-th wave of a level takes
+        // ray l * (waves of the level) + w: the 64 rays of one instruction point in different directions and touch
+        // different cells.  Step j of a ray is field base0 + j * cj + minor(j) * cm, minor(j) = (fstep * j + 2^21) >> 22:
+        // five instructions and a fire-and-forget LDS add.  Level 0 goes into the 16-bit block (first window only: it
+        // outlives the windows); the last, partial chunk of every ray is a predicated item of its own.
+        {
             const int rx0 = x0 - gx_base, ry0 = y0 - gy_base;
-            const int cjx = steep ? 0 : sx, cmx = steep ? sx : 0, cjy = steep ? sy : 0, cmy = steep ? 0 : sy;
-            // rows of the ray inside this window?  (uniform: skip whole rays / blocks)
-            const int xa = rx0, xb = rx0 + ex;
-            if (max(xa, xb) < 0 || min(xa, xb) >= rows_w) continue;
-            for (int jb = NEAR_R; jb <= dmaj; jb += 64) {
-                const int j = jb + lane;
-                const int m = (int)((fstep * (uint32_t)j + (1u << (RFIX - 1))) >> RFIX);
-                const int row = rx0 + cjx * j + cmx * m, col = ry0 + cjy * j + cmy * m;
-                if (j <= dmaj && (unsigned)row < (unsigned)rows_w) {
-                    const int c = row * stride + col;
-                    atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+            const int base0 = rx0 * stride + ry0;
+            const bool whole = S0 == S_lo && S1 == S_hi;                           // one window holds the fan: no row test
+            if (n_win == 0) {
+                const int nw0 = (v.B + 63) >> 6;
+                for (int q = wave; q < nw0; q += RB / 64) {
+                    const int b = lane * nw0 + q;
+                    if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
+                    const uint32_t fs = r_fstep[b];
+                    const uint32_t cc = r_cc[b];
+                    const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                    const int dmaj = (int)r_dmaj[b];
+                    const int mj = cj == 1 || cj == -1 ? cj : (cj > 0 ? NEAR_W : -NEAR_W);   // the same steps in the 16-bit block
+                    const int mm = cm == 1 || cm == -1 ? cm : (cm > 0 ? NEAR_W : -NEAR_W);
+                    uint32_t facc = 1u << (RFIX - 1);
+                    int aj = NEAR_R * NEAR_W + NEAR_R;
+#pragma unroll
+                    for (int u = 0; u < NEAR_R; ++u) {
+                        const int c = aj + __mul24((int)(facc >> RFIX), mm);
+                        if (u <= dmaj) atomicAdd(&mini[c >> 1], 1u << ((c & 1) * 16));
+                        facc += fs; aj += mj;
+                    }
+                }
+            }
+            const int nlev = UNI(s_nlev);                                          // levels 1 .. nlev have whole chunks
+            const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
+            for (int q = wave; q < nitems; q += RB / 64) {
+                int k = 1;
+                for (int kk = 2; kk <= nlev; ++kk) if (q >= UNI(s_lp[kk])) k = kk;
+                const int nk = UNI(s_nk[k]), nwk = (nk + 63) >> 6, wslot = q - UNI(s_lp[k]);
+                const int ii = lane * nwk + wslot;
+                if (ii >= nk) continue;
+                const int b = perm[ii];
+                const uint32_t fs = r_fstep[b];
+                const uint32_t cc = r_cc[b];
+                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                const int j0 = k * NEAR_R;
+                uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
+                int aj = base0 + __mul24(j0, cj);
+                if (whole) {
+#pragma unroll
+                    for (int u = 0; u < NEAR_R; ++u) {
+                        const int c = aj + __mul24((int)(facc >> RFIX), cm);
+                        atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+                        facc += fs; aj += cj;
+                    }
+                } else {
+                    // rows: row = rx0 + j * rj + m * rm, where (rj, rm) = (+-1, 0) for a ray along x and (0, +-1) along y
+                    const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
+                    int rowj = rx0 + j0 * rj;
+#pragma unroll
+                    for (int u = 0; u < NEAR_R; ++u) {
+                        const int m = (int)(facc >> RFIX);
+                        const int c = aj + __mul24(m, cm);
+                        if ((unsigned)(rowj + m * rm) < (unsigned)rows_w) atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+                        facc += fs; aj += cj; rowj += rj;
+                    }
+                }
+            }
+            // the partial chunk at the end of every ray with at least NEAR_R + 1 steps
+            for (int b = tid; b < v.B; b += RB) {
+                const int dmaj = (int)r_dmaj[b];
+                if (!(r_info[b] & RI_VALID) || dmaj < NEAR_R) continue;
+                const int j0 = ((dmaj + 1) / NEAR_R) * NEAR_R;                     // first step after the whole chunks
+                if (j0 > dmaj) continue;
+                const uint32_t fs = r_fstep[b];
+                const uint32_t cc = r_cc[b];
+                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
+                uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
+                int aj = base0 + __mul24(j0, cj);
+                int rowj = rx0 + j0 * rj;
+                const int left = dmaj - j0;
+#pragma unroll
+                for (int u = 0; u < NEAR_R - 1; ++u) {
+                    const int m = (int)(facc >> RFIX);
+                    const int c = aj + __mul24(m, cm);
+                    if (u <= left && (whole || (unsigned)(rowj + m * rm) < (unsigned)rows_w)) atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+                    facc += fs; aj += cj; rowj += rj;
                 }
             }
         }
@@ -533,18 +732,14 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
         }
         BAR_LDS();
         // ---- the owners put their cell's replayed value into the field of its first source, the other sources vanish ----
-        for (int b = tid; b < v.B; b += RB) {
-            const int info = r_info[b];
-            if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC)) continue;
-            for (int e = 0; e < 2; ++e) {
-                const uint32_t ov = oval[b << 1 | e];
-                if (ov == 0xFFu) continue;
-                FCell f;
-                flagged_cell(b, e, info, f);
-                if (f.sx < S0 || f.sx > S1) continue;
-                for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy)
-                    cnt8[(f.gxs[ix] - gx_base) * stride + (f.gys[iy] - gy_base)] = (ix | iy) ? (uint8_t)0 : (uint8_t)(0x80u | ov);
-            }
+        for (int pr = tid; pr < 2 * v.B; pr += RB) {
+            const uint32_t ov = oval[pr];
+            if (ov == 0xFFu) continue;
+            FCell f;
+            cell_sources(scell[pr], f);
+            if (f.sx < S0 || f.sx > S1) continue;
+            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy)
+                cnt8[(f.gxs[ix] - gx_base) * stride + (f.gys[iy] - gy_base)] = (ix | iy) ? (uint8_t)0 : (uint8_t)(0x80u | ov);
         }
         BAR_LDS();
         STAMP(6);
@@ -675,7 +870,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v) {
     }
 }
 
-void launch_map_update_ray(const DevView& v, hipStream_t s) {
+void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s) {
     const RayGeom g = ray_geom(v.B, v.reach);
     static int lds_attr = 0;
     if (g.bytes > lds_attr) {
@@ -683,7 +878,7 @@ void launch_map_update_ray(const DevView& v, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, g.bytes);
         lds_attr = g.bytes;
     }
-    hipLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, v);
+    hipLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, v, only);
 }
 
 }  // namespace rbpf

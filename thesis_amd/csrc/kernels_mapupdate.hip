@@ -724,9 +724,11 @@ void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    bool fan = false;
-    if (v.mu_mode == 0 && map_update_ray_available(v)) { launch_map_update_ray(v, s); fan = true; }
-    else if (v.mu_mode == 2 && map_update_fan_available(v)) { launch_map_update_fan(v, s); fan = true; }
+    // the chain: every kernel leaves mu_fallback[p] != 0 for the particles it could not hold
+    bool first = false;
+    if ((v.mu_mode == 0 || v.mu_mode == 2) && map_update_fan_available(v)) { launch_map_update_fan(v, s); first = true; }
+    if ((v.mu_mode == 0 || v.mu_mode == 3) && map_update_ray_available(v)) { launch_map_update_ray(v, first ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, s); first = true; }
+    const bool fan = first;
     hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, d_bad);
 }
 

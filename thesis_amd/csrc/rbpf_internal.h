@@ -51,9 +51,11 @@ struct DevView {
     float *asel_x, *asel_y; int n_asel;  // beams with BF_MATCH_ADJ, compacted
     // per-update scratch
     double*  upd_pose;                 // [3][P] poses used by the current map update
-    int32_t* mu_fallback;              // [P] 1 = the whole-fan map update gave the particle back to the window kernel
-    int mu_mode;                       // 0 = global-index kernel (kernels_mapray.hip) when the layout allows it, 1 = 128x128 windows only,
-                                       // 2 = whole-fan kernel (kernels_mapfan.hip); 0 and 2 hand what they cannot hold to the window kernel
+    int32_t* mu_fallback;              // [P] != 0: the map-update kernel that ran first gave the particle back to the next one
+    int32_t* mu_hint;                  // [3][2] (attempts, geometry give-backs) of the whole-fan kernel's last launches, rotating by step
+    int mu_step;                       // launch counter of the map update (selects the mu_hint slot)
+    int mu_mode;                       // 0 = whole-fan kernel, then the global-index kernel for what it gave back, then 128x128 windows;
+                                       // 1 = 128x128 windows only; 2 = whole-fan kernel, then windows; 3 = global-index kernel, then windows
     uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
     int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
     int32_t* dup_of; int dups_valid;    // representative of each particle's group of exact duplicates since the last resample (kernels_resample.hip); valid until the next proposal
@@ -140,7 +142,7 @@ void launch_readback(void* mapped_dst, const double* d_nan_elem, const int32_t* 
 bool map_update_fan_available(const DevView& v);
 void launch_map_update_fan(const DevView& v, hipStream_t s);
 bool map_update_ray_available(const DevView& v);
-void launch_map_update_ray(const DevView& v, hipStream_t s);
+void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
 void launch_last_scan(const DevView& v, int particle, double* d_out_xy, hipStream_t s);

@@ -14,8 +14,8 @@ bad = 0
 for case in range(N):
     cs = float(rng.choice([0.05, 0.05, 0.1, 0.025]))
     B = int(rng.choice([1, 7, 64, 180, 361, 721, 1081, 1081, 1500]))
-    kernel = os.environ.get("FUZZ_KERNEL") or str(rng.choice(["ray", "ray", "ray", "fan", "window"]))
-    if kernel != "ray":
+    kernel = os.environ.get("FUZZ_KERNEL") or str(rng.choice(["auto", "auto", "ray", "ray", "fan", "window"]))
+    if kernel != "auto":
         os.environ["RBPF_MAP_KERNEL"] = kernel
     else:
         os.environ.pop("RBPF_MAP_KERNEL", None)

@@ -10,8 +10,8 @@ B = int(os.environ.get("PROBE_B", "1081"))
 ang = synthetic.beam_angles(B)
 a, ranges, odo, poses = synthetic.make_log(12, B, period=0.7)
 CS = float(os.environ.get("PROBE_CS", "0.05"))
-for mode in os.environ.get("PROBE_KERNELS", "ray,fan,window").split(","):
-    if mode != "ray":
+for mode in os.environ.get("PROBE_KERNELS", "auto,ray,fan,window").split(","):
+    if mode != "auto":
         os.environ["RBPF_MAP_KERNEL"] = mode
     else:
         os.environ.pop("RBPF_MAP_KERNEL", None)
