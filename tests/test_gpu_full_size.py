@@ -1,0 +1,127 @@
+"""BASELINE configs[3] and [4] at their per-GPU sizes, and how often a real log leaves the fast map kernels.
+
+configs[3]: 16 384 particles over 8 GPUs = 2 048 per GPU, 1081 beams, 0.05 m, a long run.
+configs[4]: 65 536 particles over 8 GPUs = 8 192 per GPU, 181 beams (data/orebro.log), 0.025 m: 21 GB of tiles.
+At these sizes the oracle cannot follow every particle, so the tests pin (a) a few particles cell for cell against the
+oracle over the first scans, with the poses the engine itself chose read back, (b) the counters the oracle also keeps
+(ray cells, written cells), (c) size-independent properties of the whole population over the rest of the run.
+The numbers DESIGN.md quotes (fallback fractions, windows per particle) are written to gpurun_out/full_size.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, rbpf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPORT = os.path.join(os.path.dirname(HERE), "gpurun_out", "full_size.json")
+
+
+def _report(key, value):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        d = json.load(open(REPORT)) if os.path.exists(REPORT) else {}
+        d[key] = value
+        json.dump(d, open(REPORT, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _oracle_dump(cmap):
+    return {c: np.rint(t / 0.1).astype(np.int8) for c, t in cmap.tiles().items()}
+
+
+def _run_config(P, B, cs, fov, steps_checked, steps_total, probe):
+    """The bench's step (bench.Runner: IMU, scan update with both matcher stages, resample) at full size."""
+    from bench import Runner, PERIOD_S
+    from thesis_amd.datasets import synthetic
+    log = synthetic.make_log(steps_total + 3, B, period=PERIOD_S, fov=fov)
+    angles, ranges, odo, truth = log
+    r = Runner(P, B, cs, log)
+    e = r.e
+    # (a) the first scans without resampling: the probed particles' maps must equal the oracle's, fed with the poses the
+    #     engine used (its own mean poses, read back after each update)
+    lib = c_oracle.load()                                                        # the C restatement (pinned to G3 bit for bit)
+    maps = {p: c_oracle.CMap(lib, cs) for p in probe}
+    sx, sy = orc.scan_xy(ranges[0], angles)
+    for p in probe:
+        maps[p].update((0.0, 0.0, 0.0), sx, sy)
+    c0 = e.counters()
+    assert c0["ray_cells_visited"] == P * lib.orc_map_cells_visited(maps[probe[0]].h)   # all particles start at the origin
+    for k in range(steps_checked):
+        e.imu_update("velocity", odo[k], PERIOD_S * 1e4)
+        e.set_scan(ranges[k + 1], angles)
+        e.scan_update(adj=False)
+        poses = e.poses()
+        sx, sy = orc.scan_xy(ranges[k + 1], angles)
+        for p in probe:
+            maps[p].update(tuple(float(x) for x in poses[p]), sx, sy)
+    for p in probe:
+        want = _oracle_dump(maps[p])
+        got = dict(e.tiles(p))
+        assert set(got) == set(want), (p, sorted(got), sorted(want))
+        for c in want:
+            assert np.array_equal(got[c], want[c]), f"particle {p} tile {c}: {int(np.count_nonzero(got[c] != want[c]))} cells differ"
+    # (c) the rest of the run with the reference's cadence and resampling
+    r.frame = steps_checked
+    e.set_profiling(True)                                                        # restarts the counters
+    n = steps_total - steps_checked
+    for _ in range(n):
+        r.step()
+    c = e.counters()
+    poses, w, cov = e.poses(), e.weights(), e.covs()
+    assert np.all(np.isfinite(poses)) and np.all(np.isfinite(w)) and np.all(np.isfinite(cov))
+    err = np.linalg.norm(np.median(poses[:, :2], axis=0) - truth[steps_total, :2])
+    assert err < 0.5, f"the particle cloud left the simulated truth by {err:.2f} m"
+    for p in probe:
+        for _, cells in e.tiles(p):
+            assert cells.min() >= -30 and cells.max() <= 30
+    ms = e.kernel_ms("raycast")
+    out = {"particles": P, "beams": B, "cell_size": cs, "steps": n,
+           "window_fallbacks_per_particle_step": c["window_fallbacks"] / (P * n),
+           "fan_kernel_give_backs_per_particle_step": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / (P * n),
+           "ray_kernel_windows_per_particle_step": c["map_windows"] / (P * n),
+           "tiles_in_use": c["tiles_in_use"], "map_update_ms_mean": float(ms[1:].mean()) if len(ms) > 1 else None,
+           "median_position_error_m": float(err)}
+    e.close()
+    return out
+
+
+def test_config4_share_2048_particles_1081_beams_long_run():
+    out = _run_config(2048, 1081, 0.05, 1.5 * np.pi, steps_checked=4, steps_total=300, probe=(0, 1023, 2047))
+    _report("configs[3] share", out)
+    assert out["window_fallbacks_per_particle_step"] == 0.0
+    assert out["tiles_in_use"] == 2048                       # the 16 m room stays inside the first 40 m tile
+
+
+def test_config5_share_8192_particles_181_beams_0025m():
+    out = _run_config(8192, 181, 0.025, np.pi, steps_checked=3, steps_total=24, probe=(0, 4095, 8191))
+    _report("configs[4] share", out)
+    assert out["window_fallbacks_per_particle_step"] == 0.0  # every fan is 640 cells wide: strips of the global-index kernel
+    assert out["ray_kernel_windows_per_particle_step"] > 1.0
+    assert out["tiles_in_use"] == 8192
+
+
+@pytest.mark.parametrize("cs", [0.05, 0.1])
+def test_intel_head_fallback_fraction(cs):
+    """The first 70 scans of data/intel.txt through the reference's loop: how many particle-updates leave the whole-fan
+    kernel (rays up to the 15 m cap of hybridmap.py:107 make fans of up to 600 cells at 0.05 m) and how many reach the
+    128x128-window kernel at the end of the chain (none)."""
+    from thesis_amd.datasets.carmen import load_carmen
+    from thesis_amd.slam import ParticleFilter, run_log
+    log = load_carmen(os.path.join(HERE, "golden", "intel_head.log"))
+    pf = ParticleFilter(64, log.angles, motion_model="absolute", cell_size=cs)
+    pf.engine.set_profiling(True)
+    res = run_log(pf, log.scans, log.scan_times, log.odom, log.odom_times, max_frames=70, order=log.order)
+    c = pf.engine.counters()
+    n = 64 * max(1, c["scan_updates"])
+    out = {"accepted_scans": res.accepted, "map_updates": c["scan_updates"],
+           "window_fallbacks_per_particle_update": c["window_fallbacks"] / n,
+           "fan_kernel_give_backs_per_particle_update": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / n,
+           "ray_kernel_windows_per_particle_update": c["map_windows"] / n}
+    _report(f"intel_head cs={cs}", out)
+    pf.close()
+    if cs == 0.05:
+        assert out["window_fallbacks_per_particle_update"] <= 0.02

@@ -79,12 +79,12 @@ def circle_trajectory(n_steps: int, radius: float = 3.0, speed: float = 0.5,
 
 
 def make_log(n_steps: int, n_beams: int = 1081, seed: int = 1234, odo_seed: int = 1235,
-             period: float = 0.1) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+             period: float = 0.1, fov: float = 1.5 * pi) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
     """(angles[B], ranges[n_steps+1, B], odo[n_steps, 3] = (vx, vy, omega), true_poses).
 
     ``ranges[k]`` is the scan taken at ``true_poses[k]``; ``odo[k]`` moves k -> k+1 over
     ``period`` seconds, with 1 % multiplicative noise (seed ``odo_seed``)."""
-    angles = beam_angles(n_beams)
+    angles = beam_angles(n_beams, fov)
     poses = circle_trajectory(n_steps, period=period)
     rng = np.random.Generator(np.random.PCG64(seed))
     ranges = np.stack([cast_scan(p, angles, rng) for p in poses])
