@@ -14,6 +14,8 @@ Vector sets:
   G7 Robot.imu_update           G8 main.resample           G9 get_scan_match inputs
   G10 debug.mat (data file: a captured matchScanCustom argument tuple)
   G11 dataset adapters (what the Default* / Intel* loaders hand to main.py)
+  G12 the Freid101-family adapters on data/orebro.log (OberoIMUData as is; OberoLidarData with its beam count set to
+      the file's 181 - as committed it says 360 and cannot parse the file)
 """
 import contextlib
 import io
@@ -463,8 +465,24 @@ def g11():
     save("G11_dataset_adapters", **out)
 
 
+def g12():
+    """Freid101-family adapters (Freid101IMUData.py:9-32 shape) on the one log of that family that is in the tree:
+    data/orebro.log through OberoIMUData / OberoLidarData.  The lidar adapter's module constant POINTS_PER_SCAN (360,
+    OberoLidarData.py:8) is set to the 181 beams the file has before the reference's own parsing code runs; nothing
+    else is touched.  Full arrays (237 scans, 238 odometry records): the build's loader must reproduce them exactly."""
+    import OberoIMUData as ref_obero_imu
+    import OberoLidarData as ref_obero_lidar
+    out = {}
+    d, ti = quiet(ref_obero_imu.OberoIMUData().load_and_format)
+    out["oi_data"] = np.asarray(d, dtype=np.float64); out["oi_times"] = np.asarray(ti, dtype=np.int64)
+    ref_obero_lidar.POINTS_PER_SCAN = 181
+    t, sc, ang = quiet(ref_obero_lidar.OberoLidarData().load_and_format)
+    out["ol_times"] = np.asarray(t, dtype=np.int64); out["ol_scans"] = np.asarray(sc, dtype=np.float64); out["ol_angles"] = np.asarray(ang, dtype=np.float64)
+    save("G12_obero_adapters", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g69", "g7", "g8", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g69", "g7", "g8", "g10", "g11", "g12"]
     if "g1" in which: g1()
     if "g2" in which: g2()
     if "g345" in which: g3_g4_g5()
@@ -473,3 +491,4 @@ if __name__ == "__main__":
     if "g8" in which: g8()
     if "g10" in which: g10()
     if "g11" in which: g11()
+    if "g12" in which: g12()

@@ -166,6 +166,10 @@ class RunResult:
     accepted: int = 0
     resamples: int = 0
     pose0: List[np.ndarray] = field(default_factory=list)
+    # what the loop decided, event by event: ("imu", reading index, dt) and
+    # ("scan", scan index, frame, accepted, adj, last_scan refreshed); pose0_before[k] = particle 0 in front of scan event k
+    trace: List[tuple] = field(default_factory=list)
+    pose0_before: List[np.ndarray] = field(default_factory=list)
 
 
 def scan_to_global(ranges, angles, pose):
@@ -199,12 +203,16 @@ def run_log(pf: ParticleFilter, scans, scan_times, odom, odom_times, max_frames:
             dt = max(int(odom_times[i]) - int(prev_ts), 0)
             pf.imu_update(odom[i], float(dt))
             prev_ts = odom_times[i]
+            res.trace.append(("imu", i, dt))
             continue
         ranges = scans[int(rec)]                                                 # main.py:147-181
         curr = np.array(pf.particles[0].get_latest_pose())
         dist = sqrt((last_updated_pose[0] - curr[0]) ** 2 + (last_updated_pose[1] - curr[1]) ** 2)
         rot = abs(last_updated_pose[2] - curr[2])
-        if update_count < MAX_UPDATE_COUNT or dist >= DIST_THRESHOLD or rot >= ROT_THRESHOLD:
+        res.pose0_before.append(curr)
+        accepted = update_count < MAX_UPDATE_COUNT or dist >= DIST_THRESHOLD or rot >= ROT_THRESHOLD
+        res.trace.append(("scan", int(rec), frame, bool(accepted), bool(accepted and not (frame % 5 < 2)), bool(accepted and frame % 5 == 0)))
+        if accepted:
             pf.map_update(ranges, last_scan, adj=not (frame % 5 < 2))
             res.resamples += int(pf.resample())
             res.accepted += 1
