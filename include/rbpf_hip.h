@@ -140,6 +140,9 @@ int  rbpf_get_kernel_ms(rbpf_handle* h, int32_t which, double* out_ms, int32_t c
 /* ranges[B], angles[B] -> sensor-frame endpoints (host libm cos/sin, as the reference), the
  * per-beam range classes (robot.py:130, hybridmap.py:107,218) and the upload. */
 int  rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, int32_t n_beams);
+/* the same from the end points a reference Scan object holds (Scan.x(), Scan.y(), lidar.py:82-87): what the per-object
+ * facade (thesis_amd/dropin.py) has in hand when main.py:157 passes it a Scan */
+int  rbpf_set_scan_xy(rbpf_handle* h, const double* x, const double* y, int32_t n_beams);
 
 /* ---- a2: Robot.imu_update (robot.py:45-57) for every particle ------------------------------ */
 int  rbpf_imu_update(rbpf_handle* h, int32_t model, const double* data3, double dt_ticks);

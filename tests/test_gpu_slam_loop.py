@@ -262,3 +262,97 @@ def test_orebro_replay_all_scans_at_0025m():
     xs, ys = pf.particles[0]._map.get_occupied_points()
     assert len(xs) > 300                                   # walls seen at least twice (one hit is +0.8, the threshold 1.0)
     pf.close()
+
+
+def test_dropin_objects_run_the_reference_loop_body():
+    """thesis_amd.dropin: the statements of main.py:138-168 that touch particles - the two list comprehensions over
+    Robot objects, resample(particles), get_latest_pose(), from_global_reference, _map.get_occupied_points() - run over
+    the facade and give exactly what run_log gives over the batched ParticleFilter with the same seeds."""
+    from math import pi, sqrt
+    from thesis_amd import dropin
+    from thesis_amd.datasets import synthetic
+    from thesis_amd.slam import ParticleFilter, run_log
+    NUM_PARTICLES, B, T = 24, 361, 14
+    angles, ranges, odo, truth = synthetic.make_log(T, B, period=0.7)
+    scan_times = (np.arange(T + 1) * 7000).astype(np.int64)
+    odom_times = scan_times[1:] - 1
+
+    class Reading:                                    # models.py:44-77, as much as Robot.imu_update uses
+        def __init__(self, data, ts):
+            self._data, self._ts, self._dt = data, ts, 0.0
+
+        def get_data(self): return self._data
+        def timestamp(self): return self._ts
+        def set_dt(self, dt): self._dt = dt
+        def dt(self): return self._dt
+
+    dropin.configure(motion_model="velocity", cell_size=0.05, max_beams=B, seed=42)
+    particles = [dropin.Robot(None) for _ in range(NUM_PARTICLES)]                    # main.py:87
+    urng = np.random.Generator(np.random.PCG64(42))                                 # the uniforms ParticleFilter(seed=42).resample() draws
+    imu = [Reading(odo[k], int(odom_times[k])) for k in range(T)]
+    lidar = [dropin.Scan(ranges[k], angles, int(scan_times[k])) for k in range(T + 1)]
+    prev_timestamp = imu[0].timestamp()                                               # main.py:102
+    imu_idx = lidar_idx = 0
+    plotFrameNumber = 1550                                                            # main.py:110
+    last_updated_pose = particles[0].get_latest_pose()
+    last_scan = lidar[0].from_global_reference(last_updated_pose)
+    update_count = 0
+    times = np.unique(np.concatenate((odom_times, scan_times)))                       # main.py:114
+    for t in times:                                                                   # main.py:138-168
+        imu_reading = imu[imu_idx]
+        if imu_reading.timestamp() == t:
+            imu_idx = min(imu_idx + 1, len(imu) - 1)
+            dt = imu_reading.timestamp() - prev_timestamp
+            imu_reading.set_dt(dt)
+            [p.imu_update(imu_reading) for p in particles]
+            prev_timestamp = imu_reading.timestamp()
+        if int(scan_times[lidar_idx]) == t:
+            lidar_reading = lidar[lidar_idx]
+            lidar_idx = min(lidar_idx + 1, len(lidar) - 1)
+            curr_pose = particles[0].get_latest_pose()
+            dist = sqrt((last_updated_pose.x() - curr_pose.x()) ** 2 + (last_updated_pose.y() - curr_pose.y()) ** 2)
+            rot = abs(last_updated_pose.theta() - curr_pose.theta())
+            if update_count < 2 or (dist >= 0.33 or rot >= pi / 9):
+                if plotFrameNumber % 5 < 2:
+                    [p.map_update(lidar_reading, last_scan, False) for p in particles]
+                else:
+                    [p.map_update(lidar_reading, last_scan, True) for p in particles]
+                particles = dropin.resample(particles, u=float(urng.random()))
+                if dist >= 0.33 or rot >= pi / 9:
+                    update_count = 0
+                    last_updated_pose = curr_pose
+                elif update_count < 2:
+                    update_count += 1
+                if plotFrameNumber % 5 == 0:
+                    last_scan = lidar_reading.from_global_reference(particles[0].get_latest_pose())
+            plotFrameNumber += 1
+    plot_x, plot_y = particles[0]._map.get_occupied_points()
+    eng_a = particles[0]._s.filter().engine
+    # the same run through the batched loop
+    pf = ParticleFilter(NUM_PARTICLES, angles, motion_model="velocity", cell_size=0.05, seed=42)
+    res = run_log(pf, ranges, scan_times, odo, odom_times)
+    assert res.accepted >= 10
+    try:
+        np.testing.assert_array_equal(eng_a.poses(), pf.engine.poses())
+        np.testing.assert_array_equal(eng_a.weights(), pf.engine.weights())
+        np.testing.assert_array_equal(eng_a.covs(), pf.engine.covs())
+        for p in (0, NUM_PARTICLES - 1):
+            for (ca, ta), (cb, tb) in zip(eng_a.tiles(p), pf.engine.tiles(p)):
+                assert ca == cb and np.array_equal(ta, tb)
+        bx, by = pf.particles[0]._map.get_occupied_points()
+        assert np.array_equal(plot_x, bx) and np.array_equal(plot_y, by) and len(plot_x) > 500
+        # the rest of the per-object surface
+        r0 = particles[0]
+        assert len(r0.x()) == len(r0.y()) == len(r0.theta()) > T and isinstance(r0.weight(), list)
+        m = r0._map
+        cell = m.get_cell(1.0, -2.0)
+        assert (cell.x, cell.y) == (int(1.0 / 40 * 800 + 400), int(-2.0 / 40 * 800 + 400)) and m.get_cell(500.0, 0.0) is None
+        assert m.index_to_distance(400) == 0.0 and abs(m.index_to_distance(401) - 0.05) < 1e-12
+        near = m.get_nearby_occ_points(m.get_cell(7.9, 0.0))
+        assert len(near) > 10 and all(abs(x) < 10 and abs(y) < 10 for x, y in near)
+        snap = r0.copy()
+        assert snap._map.keys() == {(0.0, 0.0)} and snap._x == r0.x()
+        assert str(r0).startswith("Robot at position: Pose: (")
+    finally:
+        pf.close()
+        dropin.configure()

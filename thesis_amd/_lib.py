@@ -62,6 +62,7 @@ PROTOTYPES = {
     "rbpf_set_profiling_families": (C.c_int, [_H, C.c_uint32]),
     "rbpf_get_kernel_ms": (C.c_int, [_H, C.c_int32, _D, C.c_int32, _I]),
     "rbpf_set_scan": (C.c_int, [_H, _D, _D, C.c_int32]),
+    "rbpf_set_scan_xy": (C.c_int, [_H, _D, _D, C.c_int32]),
     "rbpf_imu_update": (C.c_int, [_H, C.c_int32, _D, C.c_double]),
     "rbpf_weight_samples": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
     "rbpf_map_update": (C.c_int, [_H, _D]),

@@ -444,10 +444,8 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
 }
 
 // ---- a1 ---------------------------------------------------------------------------------------------
-int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, int32_t B) {
-    if (!h || !ranges || !angles) return RBPF_EINVAL;
-    ON_DEVICE(h);
-    if (B < 1 || B > h->cfg.max_beams) return fail(h, RBPF_EINVAL, "n_beams out of range");
+// the scan block from sensor-frame end points: range classes, compacted matcher lists, one upload
+static int upload_scan_points(rbpf_handle* h, const double* px, const double* py, int32_t B) {
     const rbpf_config& c = h->cfg;
     const size_t MBP = ((size_t)c.max_beams + 15) & ~(size_t)15;
     unsigned char* slot = static_cast<unsigned char*>(h->ring_scan.acquire());
@@ -459,8 +457,7 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
     uint8_t* fl = slot + 3 * MBP * 8 + 4 * MBP * 4;
     int nm = 0, na = 0;
     for (int i = 0; i < B; ++i) {
-        double x = ranges[i] * cos(angles[i]);           // lidar.py:78
-        double y = ranges[i] * sin(angles[i]);           // lidar.py:79
+        const double x = px[i], y = py[i];
         double dist = sqrt(x * x + y * y);               // robot.py:129, hybridmap.py:105,217
         uint8_t f = 0;
         if (dist < c.weight_max_range && dist > c.weight_min_range) f |= BF_WEIGHT;   // robot.py:130
@@ -483,6 +480,26 @@ int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, in
     v.B = B;
     h->have_scan = true;
     return RBPF_OK;
+}
+
+int rbpf_set_scan(rbpf_handle* h, const double* ranges, const double* angles, int32_t B) {
+    if (!h || !ranges || !angles) return RBPF_EINVAL;
+    ON_DEVICE(h);
+    if (B < 1 || B > h->cfg.max_beams) return fail(h, RBPF_EINVAL, "n_beams out of range");
+    std::vector<double> x((size_t)B), y((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        x[i] = ranges[i] * cos(angles[i]);               // lidar.py:78
+        y[i] = ranges[i] * sin(angles[i]);               // lidar.py:79
+    }
+    return upload_scan_points(h, x.data(), y.data(), B);
+}
+
+// the same from a Scan object's own state: its sensor-frame end points x(), y() (lidar.py:76-87)
+int rbpf_set_scan_xy(rbpf_handle* h, const double* x, const double* y, int32_t B) {
+    if (!h || !x || !y) return RBPF_EINVAL;
+    ON_DEVICE(h);
+    if (B < 1 || B > h->cfg.max_beams) return fail(h, RBPF_EINVAL, "n_beams out of range");
+    return upload_scan_points(h, x, y, B);
 }
 
 // ---- a2 ---------------------------------------------------------------------------------------------

@@ -161,6 +161,14 @@ class ParticleEngine:
         self._check(self._lib.rbpf_set_scan(self._h, _dp(r), _dp(a), len(r)))
         self.n_beams = len(r)
 
+    def set_scan_xy(self, x, y):
+        """The scan from its sensor-frame end points (what a reference Scan object holds, lidar.py:76-87)."""
+        x, y = _f64(x), _f64(y)
+        if x.shape != y.shape or x.ndim != 1:
+            raise ValueError("x and y must be 1-D arrays of equal length")
+        self._check(self._lib.rbpf_set_scan_xy(self._h, _dp(x), _dp(y), len(x)))
+        self.n_beams = len(x)
+
     # -- a2 ------------------------------------------------------------------------------------------
     def imu_update(self, model, data, dt_ticks: float):
         mid = IMU_MODEL_IDS[model] if isinstance(model, str) else int(model)
