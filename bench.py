@@ -9,9 +9,10 @@ IMU propagation (robot.py:45-57), Robot.map_update for every particle (robot.py:
 30-sample proposal, weighting, moments, ray-cast map update) and resample (main.py:46-79), with the
 reference's scan-match cadence (main.py:156-159) and last_scan refresh (main.py:167-168).
 
-Workload (BASELINE.json configs[1]): 1024 particles per GPU, 1081 beams over 270
-degrees, 0.05 m cells, synthetic `room16` world (no 1081-beam Intel log exists).  Weak scaling: every rank
-holds 1024 particles; the per-particle weights are all-reduced over RCCL before the global resampling.
+Workload (BASELINE.json configs[2]): 4096 particles per GPU, 1081 beams over 270
+degrees, 0.05 m cells, synthetic `room16` world (data/fr101.log is not in the reference's tree).  configs[1]
+(1024 particles) and the north-star size (10 240) are measured in the same run and reported beside it.  Weak scaling:
+every rank holds 4096 particles; the per-particle weights are all-reduced over RCCL before the global resampling.
 Inputs (the scan log) are generated before the timed region; one scan (17 KB) is uploaded per step.
 
 Rank 0 prints ONE JSON line.
@@ -38,15 +39,15 @@ NDT_DEFAULT = 1
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--particles", type=int, default=1024, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=4096, help="particles per GPU")
     ap.add_argument("--beams", type=int, default=1081)
     ap.add_argument("--cell-size", type=float, default=0.05)
     ap.add_argument("--ndt", type=int, default=NDT_DEFAULT, choices=(0, 1),
                     help="second matcher stage (matchScanCustom.m:32-50, NDT refinement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-target-run", action="store_true", help="skip the extra 10 240-particle measurement")
+    ap.add_argument("--no-target-run", action="store_true", help="skip the extra 1024- and 10 240-particle measurements")
     return ap.parse_args()
 
 
@@ -109,7 +110,7 @@ class Runner:
         self.frame += 1
 
 
-KERNEL_NAMES = {"raycast": "rbpf::map_update_fan_kernel", "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
+KERNEL_NAMES = {"raycast": "rbpf::map_update_fan_kernel",        # (the family's other kernels - global-index, windows - exit at once when it gave nothing back) "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
                 "weight": "rbpf::propose_weight_kernel", "resample": "rbpf::resample_copy_kernel"}
 
 
@@ -190,7 +191,7 @@ def cpu_baseline(log, B, cell_size, seconds=12.0):
         mean, _, _ = orc.proposal_moments(g[i], w)
         hm.update(tuple(float(x) for x in mean), sx[1], sy[1])
     py_rate = py_n / (time.perf_counter() - t0)
-    return {"value": total / wall, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+    return {"value": total / wall, "unit": "particle-updates/s", "cores": cores, "kind": "port", "matcher_included": False,
             "sample": f"{total} particle-updates ({cores} threads x {n_each} particles x {n_steps} scans, B={B}, "
                       f"cs={cell_size}): C restatement of Robot.map_update (weighting + moments + ray-cast), "
                       f"scan matcher excluded (MATLAB, not timeable); single core: {1.0 / per_pu:.1f}/s",
@@ -314,8 +315,21 @@ def main():
     if c["resample_copies"]:
         alg_bytes["resample"] = 4.0 * c["bytes_copied"] / (n_upd * args.particles)
     ach = alg_bytes[dominant] * args.particles / (mean_ms[dominant] * 1e-3) / 1e9 if mean_ms[dominant] > 0 else 0.0
+    traffic = pmc_traffic(dominant, args.particles)
+    # the whole step against the same peak: SURVEY 8(d)'s bytes per particle-update (4-byte cells: cells read by matcher,
+    # weighting and ray-cast, cells written, 2 x 104 B of state) over the step time
+    bytes_pu = 8.0 * W_per_particle + 4.0 * args.beams * 2 + 208.0
+    step_ach = bytes_pu * args.particles * world / (elapsed / args.steps) / 1e9
+    n_fb = max(1, args.steps) * args.particles
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, args.particles),
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                # the same kernel in the bytes it actually moves (int8 cells; PMC FETCH/WRITE passes, profiles/)
+                "frac_stored_bytes": (traffic / (mean_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and mean_ms[dominant] > 0 else None,
+                "step_frac": step_ach / (HBM_PEAK_GBS * world),
+                "step_bytes_per_particle_update": bytes_pu,
+                "window_fallbacks_per_particle_step": c["window_fallbacks"] / n_fb,
+                "fan_kernel_give_backs_per_particle_step": sum((int(c["fallback_reasons"]) >> (16 * i)) & 0xFFFF for i in range(4)) / n_fb,
+                "global_index_kernel_windows_per_particle_step": c["map_windows"] / n_fb,
                 "algorithmic_bytes_per_particle_update": alg_bytes[dominant],
                 "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,
                 "achieved_stored_bytes_GBs": ach / 4.0,
@@ -334,7 +348,8 @@ def main():
            "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "int8 map cells (lattice log-odds), f64 poses/weights", "data": "synthetic",
-           "config": {"workload": ("BASELINE configs[1]" if (args.particles, args.beams, args.cell_size) == (1024, 1081, 0.05)
+           "config": {"workload": ("BASELINE configs[2]" if (args.particles, args.beams, args.cell_size) == (4096, 1081, 0.05)
+                                   else "BASELINE configs[1]" if (args.particles, args.beams, args.cell_size) == (1024, 1081, 0.05)
                                    else "non-default size") +
                                   f": room16 synthetic, {args.particles} particles/GPU, "
                                   f"{args.beams} beams, {args.cell_size} m grid, K=30 samples, "
@@ -354,26 +369,32 @@ def main():
         roofline["peak_measured_copy"] = copy_peak_gbs(torch)        # after the timed region, on an idle device
         roofline["frac_of_measured_copy"] = ach / roofline["peak_measured_copy"]
     if not args.no_target_run and world == 1:
-        # north-star target size: >= 10k particles x 1081 beams on one GPU (not `value`)
-        big = Runner(10240, args.beams, args.cell_size, log, ndt=args.ndt)
-        for _ in range(3):
-            big.step()
-        big.e.set_profiling(True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nb = min(args.steps, 20)
-        for _ in range(nb):
-            big.step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        km = {k: (float(x.mean()) if len(x) else 0.0)
-              for k, x in ((k, big.e.kernel_ms(k)) for k in ("raycast", "weight", "resample", "match", "ndt"))}
-        cb = big.e.counters()
-        Wb = cb["cells_written"] / (nb * 10240)
-        out["target_10k"] = {"particles": 10240, "value": 10240 * nb / dt, "ms_per_step": 1e3 * dt / nb,
-                             "kernel_ms_mean": km,
-                             "raycast_frac_of_hbm_peak": 8.0 * Wb * 10240 / (km["raycast"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        big.e.close()
+        # the same step at configs[1] (1024 particles) and at the north-star size (>= 10k particles x 1081 beams on one
+        # GPU): reported beside `value`, not in it
+        for name, Pn in (("config1_1024", 1024), ("target_10k", 10240)):
+            if Pn == args.particles:
+                continue
+            big = Runner(Pn, args.beams, args.cell_size, log, ndt=args.ndt)
+            for _ in range(3):
+                big.step()
+            big.e.set_profiling(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nb = min(args.steps, 40)
+            for _ in range(nb):
+                big.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            km = {k: (float(x.mean()) if len(x) else 0.0)
+                  for k, x in ((k, big.e.kernel_ms(k)) for k in ("raycast", "weight", "resample", "match", "ndt"))}
+            cb = big.e.counters()
+            Wb = cb["cells_written"] / (nb * Pn)
+            out[name] = {"particles": Pn, "value": Pn * nb / dt, "ms_per_step": 1e3 * dt / nb, "steps": nb,
+                         "kernel_ms_mean": km,
+                         "raycast_frac_of_hbm_peak": 8.0 * Wb * Pn / (km["raycast"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_frac": (8.0 * Wb + 4.0 * args.beams * 2 + 208.0) * Pn / (dt / nb) / 1e9 / HBM_PEAK_GBS,
+                         "window_fallbacks_per_particle_step": cb["window_fallbacks"] / (nb * Pn)}
+            big.e.close()
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(log, args.beams, args.cell_size)
     sys.stdout.flush()
