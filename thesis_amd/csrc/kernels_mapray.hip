@@ -93,7 +93,7 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
 // the flagged-cell pass borrows the counter window: 16-bit event counts, ECAP events per pair, the special list
 __host__ __device__ inline bool ray_lists_fit(const RayGeom& g) {
     const int npair = 2 * g.bpad;
-    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + 4 * g.bpad * 4 <= g.ncell;       // and room for at least 4 candidates per beam
+    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + g.bpad * 2 <= g.ncell;   // + the sorted ray records and the list of beams in play
 }
 
 bool map_update_ray_available(const DevView& v) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];
     __shared__ int s_wsum[RB / 64];
-    __shared__ int s_nslow, s_written, s_nspec, s_ncand;
+    __shared__ int s_nslow, s_written, s_nspec, s_nact;
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
 
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     if (tid == 0) {
         s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
-        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_ncand = 0;
+        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_nact = 0;
     }
     for (int i = tid; i < LL; i += RB) { s_need[i] = 0; s_tab[i] = tab[i]; }
     bins32[tid] = 0;
@@ -410,7 +410,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         if (gyb[ay + 1 - fyl]) f.gys[f.ngy++] = ay + 1;
     };
     auto old_value = [&](const FCell& f) {
-        const int a = f.sx / v.dim, bb = f.sy / v.dim;
+        const int a = a0 + (f.sx >= (a0 + 1) * v.dim ? 1 : 0) - (f.sx < a0 * v.dim ? 1 : 0);   // rays are shorter than a tile
+        const int bb = b0 + (f.sy >= (b0 + 1) * v.dim ? 1 : 0) - (f.sy < b0 * v.dim ? 1 : 0);
         const int tile = s_need[a * v.L + bb] ? s_tab[a * v.L + bb] : -1;
         return tile >= 0 ? (int)v.pool[(size_t)tile * v.dim * v.dim + (size_t)(f.sx - a * v.dim) * v.dim + (f.sy - bb * v.dim)] : 0;
     };
@@ -457,91 +458,161 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         for (int i = tid; i < npair / 4; i += RB) reinterpret_cast<uint32_t*>(pflag)[i] = 0;
     }
     BAR_LDS();
-    for (int q = tid; q < UNI(bkt_end(8 * NBIN - 1)); q += RB) rpos[brays[q]] = (uint16_t)q;
+    // the sorted order as packed records: one 8-byte read per candidate ray
+    uint2* const srec = reinterpret_cast<uint2*>(spl + RSPEC);                     // [B] {slope | OCC << 24 | NEAR << 25, dmaj | beam << 16}
+    uint16_t* const alist = reinterpret_cast<uint16_t*>(srec + G.bpad);            // [B] beams with a cell in play
+    for (int q = tid; q < UNI(bkt_end(8 * NBIN - 1)); q += RB) {
+        const int rb = brays[q];
+        rpos[rb] = (uint16_t)q;
+        const int info = r_info[rb];
+        srec[q] = make_uint2(r_fstep[rb] | ((info & RI_OCC) ? 1u << 24 : 0u) | ((info & RI_NEAR) ? 1u << 25 : 0u),
+                             (uint32_t)r_dmaj[rb] | ((uint32_t)rb << 16));
+    }
     BAR_LDS();
     STAMP(2);
-    // ---- pass 1: every pair finds the run of its own class that can reach its cell and lists it as candidates ----
-    uint32_t* const cand = reinterpret_cast<uint32_t*>(spl + RSPEC);               // [ncand_cap] pair << 16 | position in brays
-    const int ncand_cap = (G.ncell - (npair * 2 + npair * ECAP * 2 + RSPEC * 2)) / 4;
-    for (int b = tid; b < v.B; b += RB) {
+    // ---- pass 1: one lane per beam scans its neighbours in slope order once, for its end cell and the cell before it ----
+    // In the frame of the beam's class a storage cell's global source cells are the major steps {j1, j2} x the minor
+    // offsets {c1, c2} (the second of each only where the index map repeats a cell); a ray of the class crosses the cell
+    // iff minor(j) is c1 or c2 for one of those j it reaches.
+    // Beams with a cell in play, listed in the order of perm (rays by falling length): the lanes of a wave then scan
+    // windows of similar width (a window holds ~ 1/j of a class's rays), so that few lanes wait for a long scan.
+    {
+        const int n1 = UNI(s_nk[1]);                                               // rays in perm; the shorter ones follow in beam order
+        for (int i0 = 0; i0 < n1 + v.B; i0 += RB) {                                // wave-uniform trip count (ballot)
+            const int i = i0 + tid;
+            int b = -1;
+            if (i < n1) b = perm[i];
+            else if (i - n1 < v.B && ((int)r_dmaj[i - n1] + 1) / NEAR_R - 1 < 1) b = i - n1;
+            bool any = false;
+            if (b >= 0 && (r_info[b] & (RI_VALID | RI_OCC)) == (RI_VALID | RI_OCC)) {
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t sc = scell[2 * b + e];
+                    if (sc == 0xFFFFFFFFu) break;
+                    // a smaller pair on the same storage cell: this one cannot be the owner (the other duplicates show up in the scan)
+                    bool dup = e == 1 && scell[2 * b] == sc;
+                    if (b >= 1) dup = dup || scell[2 * b - 2] == sc || scell[2 * b - 1] == sc;
+                    if (b >= 2) dup = dup || scell[2 * b - 4] == sc;
+                    if (!dup) { any = true; pflag[2 * b + e] = 3; }                  // 3 = in play, not classified yet
+                }
+            }
+            const unsigned long long mask = __ballot(any);
+            int base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&s_nact, __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (any) alist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)b;
+        }
+    }
+    BAR_LDS();
+    for (int it = tid; it < UNI(s_nact); it += RB) {                               // dense: (almost) every lane has a beam with work
+        const int b = alist[it];
+        const int info_b = r_info[b];
+        const int32_t re_b = r_end[b];
+        const int ex = (int)(int16_t)(re_b & 0xFFFF), ey = (int)(int16_t)((uint32_t)re_b >> 16);
+        const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+        const int steep = aey > aex, dmaj_b = steep ? aey : aex;
+        const int smaj = steep ? (ey > 0 ? 1 : -1) : (ex > 0 ? 1 : -1), smin = steep ? (ex > 0 ? 1 : -1) : (ey > 0 ? 1 : -1);
+        const int cls = steep * 4 + (ex > 0 ? 2 : 0) + (ey > 0 ? 1 : 0);
+        const int cst = bkt_start(cls * NBIN), cen = bkt_end(cls * NBIN + NBIN - 1);
+        // the two cells: (storage cell, sources in the class frame, window on minor(dmaj_b), state)
+        int cj1[2], cj2[2], cc1[2], cc2[2], oldv[2], nev[2];
+        bool act[2];
+        int lo = INT_MAX, hi = -1;
+#pragma unroll
         for (int e = 0; e < 2; ++e) {
             const uint32_t sc = scell[2 * b + e];
-            if (sc == 0xFFFFFFFFu) break;
-            // a smaller pair on the same storage cell: this one cannot be the owner (the rest of the duplicates show up in pass 3)
-            bool dup = e == 1 && scell[2 * b] == sc;
-            if (b >= 1) dup = dup || scell[2 * b - 2] == sc || scell[2 * b - 1] == sc;
-            if (b >= 2) dup = dup || scell[2 * b - 4] == sc;
-            if (dup) continue;
+            act[e] = pflag[2 * b + e] == 3;
+            nev[e] = 0; cj1[e] = cj2[e] = cc1[e] = cc2[e] = -1; oldv[e] = 0;
+            if (!act[e]) continue;
             FCell f;
             cell_sources(sc, f);
-            const int oldv = old_value(f);                                         // in flight during the search
+            oldv[e] = old_value(f);                                                // in flight during the scan
             const int mykey = b << 1 | e;
-            RayP me;
-            load_ray(b, me);
-            // the cell in the frame of b's class: major distance j, minor offset c of every source
-            const int jg = me.dmaj - e;                                            // b itself crosses the cell at step jg
-            int lo = INT_MAX, hi = -1;                                             // window on minor(jg) of a ray that can reach a source
             bool near_cell = false, special = false;
+            // sources along the major and the minor axis of the class frame
+            const int* gmaj = steep ? f.gys : f.gxs; const int nmaj = steep ? f.ngy : f.ngx;
+            const int* gmin = steep ? f.gxs : f.gys; const int nmin = steep ? f.ngx : f.ngy;
+            const int omaj = steep ? y0 : x0, omin = steep ? x0 : y0;
+            cj1[e] = (gmaj[0] - omaj) * smaj; if (nmaj > 1) cj2[e] = (gmaj[1] - omaj) * smaj;
+            cc1[e] = (gmin[0] - omin) * smin; if (nmin > 1) cc2[e] = (gmin[1] - omin) * smin;
+            const int jmin = nmaj > 1 ? min(cj1[e], cj2[e]) : cj1[e], jmax = nmaj > 1 ? max(cj1[e], cj2[e]) : cj1[e];
+            const int cmin = nmin > 1 ? min(cc1[e], cc2[e]) : cc1[e], cmax = nmin > 1 ? max(cc1[e], cc2[e]) : cc1[e];
             for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
                 const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
                 if (max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy) < NEAR_R) near_cell = true;
-                const int js = (me.steep ? ddy : ddx) * me.smaj, cs_ = (me.steep ? ddx : ddy) * me.smin;
-                if (cs_ <= 0 || cs_ >= js) special = true;                           // an axis or a diagonal through the sensor: other classes reach it
-                const int w = js != jg ? 1 : 0;
-                lo = min(lo, cs_ - w); hi = max(hi, cs_ + w);
             }
+            if (cmin <= 0 || cmax >= jmin) special = true;                           // an axis or a diagonal through the sensor: other classes reach it
             if (near_cell) {   // most rays cross it: the wave-wide scan over all beams; claimed through bit 15 of the first source's 16-bit field
                 const int mi = (f.gxs[0] - x0 + NEAR_R) * NEAR_W + (f.gys[0] - y0 + NEAR_R), sh = (mi & 1) * 16;
                 if (!((atomicOr(&mini[mi >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
                     const int pos = atomicAdd(&s_nslow, 1);
                     if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
                 }
+                act[e] = false; pflag[mykey] = 0;
                 continue;
             }
-            const int cls = me.steep * 4 + (me.ex > 0 ? 2 : 0) + (me.ey > 0 ? 1 : 0);
-            const int cst = bkt_start(cls * NBIN), cen = bkt_end(cls * NBIN + NBIN - 1);
-            // the class is sorted by slope, so minor(jg) never decreases along it: the run is contiguous around b
-            const int q0 = rpos[b];
-            int ql = q0, qr = q0 + 1;
-            while (ql > cst && (int)((r_fstep[brays[ql - 1]] * (uint32_t)jg + (1u << (RFIX - 1))) >> RFIX) >= lo) --ql;
-            while (qr < cen && (int)((r_fstep[brays[qr]] * (uint32_t)jg + (1u << (RFIX - 1))) >> RFIX) <= hi) ++qr;
-            const int n = qr - ql;
-            const int off = atomicAdd(&s_ncand, n);
-            if (off + n <= ncand_cap) { for (int t = 0; t < n; ++t) cand[off + t] = ((uint32_t)mykey << 16) | (uint32_t)(ql + t); }
-            else s_fb = 1;
-            oldv8[mykey] = (uint8_t)oldv;
+            // window on minor(dmaj_b) of a ray that can reach a source: minor() never decreases and moves by at most one
+            // per major step, so minor(js) = cs needs minor(dmaj_b) in [cs, cs + (dmaj_b - js)] (js <= dmaj_b) or
+            // [cs - (js - dmaj_b), cs] (js > dmaj_b)
+            lo = min(lo, cmin - max(0, jmax - dmaj_b)); hi = max(hi, cmax + max(0, dmaj_b - jmin));
             pflag[mykey] = special ? 2 : 1;
             if (special) {
                 const int pos = atomicAdd(&s_nspec, 1);
                 if (pos < RSPEC) spl[pos] = (uint16_t)mykey; else s_fb = 1;
             }
         }
+        if (!act[0] && !act[1]) continue;
+        const int q0 = rpos[b];
+        for (int dir = 0; dir < 2; ++dir) {                                         // dir 0: b and the steeper slopes, dir 1: the flatter ones
+            for (int q = dir ? q0 - 1 : q0; dir ? q >= cst : q < cen; q += dir ? -1 : 1) {
+                const uint2 rr = srec[q];
+                const uint32_t fs = rr.x & 0xFFFFFFu;
+                const int dmaj_r = (int)(rr.y & 0xFFFFu), rb = (int)(rr.y >> 16);
+                const int mg = (int)((fs * (uint32_t)dmaj_b + (1u << (RFIX - 1))) >> RFIX);
+                if (dir ? mg < lo : mg > hi) break;                                 // sorted by slope: nothing further can reach a cell
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (!act[e]) continue;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const int jj = w ? cj2[e] : cj1[e];
+                        if (jj < 0 || jj > dmaj_r) continue;
+                        const int m = (int)((fs * (uint32_t)jj + (1u << (RFIX - 1))) >> RFIX);
+                        if (m != cc1[e] && m != cc2[e]) continue;
+                        const int rem = dmaj_r - jj;
+                        const bool occ_r = (rr.x >> 24) & 1u, nearev = rem == 1 && ((rr.x >> 25) & 1u);
+                        const int rank = rem == 0 ? (occ_r ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+                        const int mykey = b << 1 | e;
+                        if ((rank == EV_OCC && (rb << 1) < mykey) || (nearev && (rb << 1 | 1) < mykey)) { act[e] = false; break; }
+                        uint16_t* const myev = evl + mykey * ECAP;
+                        if (nev[e] < ECAP) myev[nev[e]] = (uint16_t)(rb << 3 | rank);
+                        ++nev[e];
+                        if (nearev) { if (nev[e] < ECAP) myev[nev[e]] = (uint16_t)(rb << 3 | EV_NEAR); ++nev[e]; }
+                    }
+                }
+                if (!act[0] && !act[1]) break;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!act[e]) { if (pflag[b << 1 | e]) pflag[b << 1 | e] = 0; continue; }
+            const int mykey = b << 1 | e;
+            oldv8[mykey] = (uint8_t)oldv[e];
+            if (pflag[mykey] == 2) {                                               // the other classes add their events in pass 2
+                atomicAdd(&evn32[mykey >> 1], (uint32_t)nev[e] << ((mykey & 1) * 16));
+                continue;
+            }
+            if (nev[e] > ECAP) {
+                const int pos = atomicAdd(&s_nslow, 1);
+                if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
+                continue;
+            }
+            const uint16_t* myev = evl + mykey * ECAP;
+            const int val = nev[e] <= 8 ? replay_sorted<8>(myev, nev[e], oldv[e], v.cc) : replay_sorted<ECAP>(myev, nev[e], oldv[e], v.cc);
+            oval[mykey] = (uint8_t)(val - v.cc.vmin);
+        }
     }
     BAR_LDS();
     STAMP(3);
-    // ---- pass 2a: one lane per candidate ----
-    {
-        const int ncand = UNI(min(s_ncand, ncand_cap));
-        for (int t = tid; t < ncand; t += RB) {
-            const uint32_t cd = cand[t];
-            const int pair = (int)(cd >> 16), rb = brays[cd & 0xFFFFu];
-            RayP r;
-            load_ray(rb, r);
-            FCell f;
-            cell_sources(scell[pair], f);
-            const int psh = (pair & 1) * 16;
-            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
-                int rank; bool nearev;
-                if (!ray_hits(r, f.gxs[ix] - x0, f.gys[iy] - y0, rank, nearev)) continue;
-                int pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
-                if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | rank);
-                if (nearev) {
-                    pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
-                    if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | EV_NEAR);
-                }
-            }
-        }
-    }
     // ---- pass 2b: cells other classes reach too; one lane per (cell, other class) ----
     {
         const int nspec = UNI(min(s_nspec, RSPEC));
@@ -583,9 +654,10 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         }
     }
     BAR_LDS();
-    // ---- pass 3: every pair with events checks that it owns its cell, sorts the events and replays them ----
-    for (int pair = tid; pair < 2 * v.B; pair += RB) {
-        if (!pflag[pair]) continue;
+    // ---- pass 3: the cells of pass 2: owner check, sort, replay ----
+    for (int it = tid; it < UNI(min(s_nspec, RSPEC)); it += RB) {
+        const int pair = spl[it];
+        if (pflag[pair] != 2) continue;                                          // abandoned in pass 1: a smaller pair owns the cell
         const int m = (int)((evn32[pair >> 1] >> ((pair & 1) * 16)) & 0xFFFFu);
         if (m > ECAP) {                                                          // (duplicates may both land here: same value twice)
             const int pos = atomicAdd(&s_nslow, 1);
@@ -603,7 +675,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         oval[pair] = (uint8_t)(val - v.cc.vmin);
     }
     BAR_LDS();
-    if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW || UNI(s_nspec) > RSPEC || UNI(s_ncand) > ncand_cap ? 3 : 2); }
+    if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW || UNI(s_nspec) > RSPEC ? 3 : 2); }
     {   // cells near the sensor and cells with more than ECAP events: one wave each, exact membership test over all beams
         const int nslow = UNI(s_nslow);
         for (int k = wave; k < nslow; k += RB / 64) {
