@@ -153,8 +153,14 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     }
     __syncthreads();
 
-    // ---- weighting: K gathers per beam, samples in chunks of WCH: the samples of a beam end on
-    //      neighbouring cells, so a large chunk re-uses the cache lines while they are still in L1 --------------
+    // ---- weighting: K gathers per beam.  The samples of a beam end on neighbouring cells (one or two cache lines), so
+    //      a beam's K look-ups are done together.  Eight at a time: eight cell addresses in the particle's home tile are
+    //      formed without a branch, the eight byte loads are issued back to back, then added - nothing waits on a single
+    //      load.  A look-up that is not safely inside a cell of the home tile (lookup_cell_home) is rare and goes the
+    //      general, exact way afterwards. -------------------------------------------------------------------------
+    const HomeTile home = home_tile(v, s_tab, s_mean[0], s_mean[1]);
+    const int8_t* const hbase = home.ok ? home.base : v.pool;
+    const double inv_cs = (double)v.dim / v.tile_len, half_safe = 0.5 - 1e-6;
     for (int k0 = 0; k0 < K; k0 += WCH) {
         int acc[WCH];
 #pragma unroll
@@ -163,12 +169,34 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
             if (!(v.bflags[b] & BF_WEIGHT)) continue;                 // robot.py:130
             const double x = v.bx[b], y = v.by[b];
 #pragma unroll
-            for (int k = 0; k < WCH; ++k) {
-                if (k0 + k < K) {
-                    double gx = (s_c[k0 + k] * x + (-s_s[k0 + k]) * y) + s_g[k0 + k][0];   // lidar.py:123
-                    double gy = (s_s[k0 + k] * x + s_c[k0 + k] * y) + s_g[k0 + k][1];
-                    int val;
-                    if (lookup_cell_fast_b(v, s_tab, s_base, gx, gy, val)) acc[k] += val;
+            for (int kb = 0; kb < WCH; kb += 8) {
+                if (k0 + kb >= K) break;                              // uniform
+                int addr[8]; bool fast[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + kb + u, K - 1);
+                    const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];   // lidar.py:123
+                    const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
+                    const double cx = gx * inv_cs, cy = gy * inv_cs;              // in cells
+                    const double fx = __builtin_floor(cx), fy = __builtin_floor(cy);
+                    const int ix = (int)fx + home.off_x, iy = (int)fy + home.off_y;
+                    fast[u] = home.ok && k0 + kb + u < K && fabs((cx - fx) - 0.5) < half_safe && fabs((cy - fy) - 0.5) < half_safe &&
+                              max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim;
+                    addr[u] = fast[u] ? (int)__umul24(ix, v.dim) + iy : 0;
+                }
+                int val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) val[u] = hbase[addr[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (fast[u]) acc[kb + u] += val[u];
+                    else if (k0 + kb + u < K) {
+                        const int k = k0 + kb + u;
+                        const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];
+                        const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
+                        int vv;
+                        if (lookup_cell_fast_b(v, s_tab, s_base, gx, gy, vv)) acc[kb + u] += vv;
+                    }
                 }
             }
         }

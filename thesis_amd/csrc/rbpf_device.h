@@ -67,6 +67,37 @@ __device__ __forceinline__ bool lookup_cell_fast_b(const DevView& v, const int32
     return true;
 }
 
+// The same again with the common case first: the position lies in the particle's HOME tile (the one that holds its pose:
+// almost every end point of a scan does).  The global cell number floor(x / cell_size) minus the tile's first cell IS the
+// reference's index whenever it is safely inside a cell (see lookup_cell_fast), so the lattice arithmetic and the table
+// read are skipped; everything else goes the general way.
+struct HomeTile { const int8_t* base; int off_x, off_y; int ok; };
+__device__ __forceinline__ HomeTile home_tile(const DevView& v, const int32_t* __restrict__ tab, double px, double py) {
+    HomeTile h; h.base = nullptr; h.off_x = h.off_y = 0; h.ok = 0;
+    int lx, ly;
+    if ((v.dim & 1) || !tile_of_coord(px, v.tile_len, v.R, lx) || !tile_of_coord(py, v.tile_len, v.R, ly)) return h;
+    const int t = tab[(lx + v.R) * v.L + (ly + v.R)];
+    if (t < 0) return h;
+    h.base = v.pool + (size_t)t * v.dim * v.dim;
+    h.off_x = v.dim / 2 - lx * v.dim; h.off_y = v.dim / 2 - ly * v.dim;
+    h.ok = 1;
+    return h;
+}
+__device__ __forceinline__ bool lookup_cell_home(const DevView& v, const HomeTile& h, const int32_t* __restrict__ tab,
+                                                 const unsigned long long* __restrict__ base, double gx, double gy, int& val) {
+    const double inv_cs = (double)v.dim / v.tile_len;
+    const double cx = gx * inv_cs, cy = gy * inv_cs;                               // in cells
+    const double fx = __builtin_floor(cx), fy = __builtin_floor(cy);
+    const double rx = cx - fx, ry = cy - fy;
+    const double eps = 1e-6;
+    const int ix = (int)fx + h.off_x, iy = (int)fy + h.off_y;
+    if (h.ok && rx > eps && rx < 1 - eps && ry > eps && ry < 1 - eps && (unsigned)ix < (unsigned)v.dim && (unsigned)iy < (unsigned)v.dim) {
+        val = h.base[__umul24(ix, v.dim) + iy];
+        return true;
+    }
+    return lookup_cell_fast_b(v, tab, base, gx, gy, val);
+}
+
 // robot.py:75-77 for a particle on the NaN-covariance branch: weight += (1 + sum of the log-odds under the scan at the
 // latest pose) * 1, evaluated on the map AFTER its update.  Whole workgroup (contains barriers).
 __device__ inline void nan_branch_weight(const DevView& v, int p, int tid, int nthreads) {
