@@ -340,6 +340,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         const int i = lc + gy_base - fyl;
         gym[lc] = (i >= 0 && i < nfx && gyb[i]) ? 0xFFu : 0u;
     }
+    uint32_t* const farh = cnt;                                                // [8 * NBIN] 16-bit counts of the rays longer than the 16-bit block (the window is not in use yet)
+    farh[tid] = 0;
     {   // bucket fill pointers: exclusive prefix sum over the 2048 (class, bucket) counts, two per thread
         const uint32_t w2 = bins32[tid];
         const int c0 = (int)(w2 & 0xFFFFu), c1 = (int)(w2 >> 16), pc = c0 + c1;
@@ -367,23 +369,28 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         r_cc[b] = ((uint32_t)cj & 0xFFFFu) | ((uint32_t)cm << 16);
         const int nfull = ((int)r_dmaj[b] + 1) / NEAR_R - 1;
         if (nfull >= 1) perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
+        if ((int)r_dmaj[b] >= NEAR_R) atomicAdd(&farh[key >> 1], 1u << sh);            // only these reach the 8-bit fields
     }
     BAR_LDS();
     // bucket key -> [start, end) in brays (the fill pointers have advanced to the bucket ends)
     auto bkt_start = [&](int key) { return key ? (int)bins16[key - 1] : 0; };
     auto bkt_end = [&](int key) { return (int)bins16[key]; };
     {   // no 8-bit field can overflow: a cell at major distance j >= NEAR_R is hit, per direction class, only by rays
-        // whose slope lies in a window of width 2^RFIX / j + 1 <= 2^18 + 1, i.e. in at most 18 consecutive buckets
+        // that are at least that long and whose slope lies in a window of width 2^RFIX / j + 1 <= 2^18 + 1, i.e. in at most
+        // 18 consecutive buckets
+        const uint16_t* fh = reinterpret_cast<const uint16_t*>(farh);
         int mx = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int key = 2 * tid + k, cls = key / NBIN, bin = key % NBIN;
-            const int hi = cls * NBIN + min(bin + 17, NBIN - 1);
-            mx = max(mx, bkt_end(hi) - bkt_start(key));
+            int sum = 0;
+            for (int d = 0; d < 18 && bin + d < NBIN; ++d) sum += fh[cls * NBIN + bin + d];
+            mx = max(mx, sum);
         }
         mx = wave_max(mx);
         if (lane == 0 && mx > HIT_BOUND) s_fb = 1;
     }
+    BAR_LDS();                                                                 // the window's first words become event counts next
     STAMP(1);
 
     // ---- flagged cells: those that receive an "occupied" or "nearby" hit (hybridmap.py:113,137,139-142) --------------
@@ -440,7 +447,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int key = 2 * tid + k, st = bkt_start(key), en = bkt_end(key);
-            if (en - st > 12) s_fb = 1;                                             // (a regular scan has one or two rays per bucket)
+            if (en - st > 64) s_fb = 1;                                             // (a regular scan has one or two rays per bucket; rays that end on a
+                                                                                    // near surface share end cells, hence slopes: a dozen or two)
             else for (int i = st + 1; i < en; ++i) {
                 const int rb = brays[i];
                 const uint32_t fbase = (uint32_t)(key % NBIN) << BIN_SHIFT;          // slopes of a bucket differ in their low 14 (15 in the last) bits
