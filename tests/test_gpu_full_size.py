@@ -125,3 +125,39 @@ def test_intel_head_fallback_fraction(cs):
     pf.close()
     if cs == 0.05:
         assert out["window_fallbacks_per_particle_update"] <= 0.02
+
+
+def test_fans_too_large_for_the_whole_fan_kernel_go_to_the_global_index_kernel():
+    """15 m rays all round at 0.05 m: 600-cell fans, twice the whole-fan kernel's window.  The first launch finds that out
+    per particle after its setup; from the second launch on the kernel leaves the particles to the global-index kernel
+    at once (every 16th still tries: `mu_hint`).  Cell-exact against the C oracle for a few particles, no particle
+    reaches the 128x128-window kernel."""
+    from thesis_amd.engine import ParticleEngine
+    P, B = 96, 721
+    ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
+    rng = np.random.Generator(np.random.PCG64(5))
+    e = ParticleEngine(P, max_beams=B, pool_tiles=8 * P)
+    lib = c_oracle.load()
+    probe = (0, 17, 95)
+    maps = {p: c_oracle.CMap(lib, 0.05) for p in probe}
+    poses = np.column_stack([rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(-3, 3, P)])
+    n_scans = 4
+    for k in range(n_scans):
+        r = 13.0 + 1.5 * np.sin(5 * ang + k) + rng.normal(0, 0.01, B)          # 11.5 .. 14.5 m, under the 15 m cap
+        e.set_scan(r, ang)
+        e.map_update(poses)
+        sx, sy = orc.scan_xy(r, ang)
+        for p in probe:
+            maps[p].update(poses[p], sx, sy)
+        poses = poses + [0.2, -0.1, 0.05]
+    c = e.counters()
+    for p in probe:
+        want = _oracle_dump(maps[p])
+        got = dict(e.tiles(p))
+        assert set(got) == set(want)
+        for cc in want:
+            assert np.array_equal(got[cc], want[cc]), f"particle {p} tile {cc}"
+    geometry = c["fallback_reasons"] & 0xFFFF
+    assert c["window_fallbacks"] == 0 and geometry == P * n_scans            # every particle left the whole-fan kernel every time ...
+    assert c["map_windows"] >= 2 * P * n_scans                               # ... and needed several strips in the global-index kernel
+    e.close()
