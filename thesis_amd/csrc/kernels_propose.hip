@@ -180,17 +180,21 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
                     const double cx = gx * inv_cs, cy = gy * inv_cs;              // in cells
                     const double fx = __builtin_floor(cx), fy = __builtin_floor(cy);
                     const int ix = (int)fx + home.off_x, iy = (int)fy + home.off_y;
-                    fast[u] = home.ok && k0 + kb + u < K && fabs((cx - fx) - 0.5) < half_safe && fabs((cy - fy) - 0.5) < half_safe &&
-                              max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim;
+                    // safely inside a cell on both axes: one minimum, one comparison (each comparison costs scalar mask work)
+                    const double margin = fmin(half_safe - fabs((cx - fx) - 0.5), half_safe - fabs((cy - fy) - 0.5));
+                    fast[u] = home.ok && k0 + kb + u < K && margin > 0.0 && max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim;
                     addr[u] = fast[u] ? (int)__umul24(ix, v.dim) + iy : 0;
                 }
                 int val[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) val[u] = hbase[addr[u]];
+                // (the empty statement keeps the eight loads together: the compiler would otherwise sink each into the
+                // branch that uses it and wait for it there, one load at a time)
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if (fast[u]) acc[kb + u] += val[u];
-                    else if (k0 + kb + u < K) {
+                    acc[kb + u] += fast[u] ? val[u] : 0;
+                    if (!fast[u] && k0 + kb + u < K) {
                         const int k = k0 + kb + u;
                         const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];
                         const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
