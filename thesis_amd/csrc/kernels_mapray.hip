@@ -93,7 +93,7 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
 // the flagged-cell pass borrows the counter window: 16-bit event counts, ECAP events per pair, the special list
 __host__ __device__ inline bool ray_lists_fit(const RayGeom& g) {
     const int npair = 2 * g.bpad;
-    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + g.bpad * 2 <= g.ncell;   // + the sorted ray records and the list of beams in play
+    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + npair * 2 <= g.ncell;    // + the sorted ray records and the list of pairs in play
 }
 
 bool map_update_ray_available(const DevView& v) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];
     __shared__ int s_wsum[RB / 64];
-    __shared__ int s_nslow, s_written, s_nspec, s_nact;
+    __shared__ int s_nslow, s_written, s_nspec, s_nact, s_exact;
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
 
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     if (tid == 0) {
         s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
-        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_nact = 0;
+        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_nact = 0; s_exact = 0;
     }
     for (int i = tid; i < LL; i += RB) { s_need[i] = 0; s_tab[i] = tab[i]; }
     bins32[tid] = 0;
@@ -377,18 +377,30 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     auto bkt_end = [&](int key) { return (int)bins16[key]; };
     {   // no 8-bit field can overflow: a cell at major distance j >= NEAR_R is hit, per direction class, only by rays
         // that are at least that long and whose slope lies in a window of width 2^RFIX / j + 1 <= 2^18 + 1, i.e. in at most
-        // 18 consecutive buckets
-        const uint16_t* fh = reinterpret_cast<const uint16_t*>(farh);
+        // 18 consecutive buckets.  First with all rays of the buckets (two reads of the fill pointers); only when that
+        // bound fails, with the rays that are long enough to reach an 8-bit field.
         int mx = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int key = 2 * tid + k, cls = key / NBIN, bin = key % NBIN;
-            int sum = 0;
-            for (int d = 0; d < 18 && bin + d < NBIN; ++d) sum += fh[cls * NBIN + bin + d];
-            mx = max(mx, sum);
+            mx = max(mx, bkt_end(cls * NBIN + min(bin + 17, NBIN - 1)) - bkt_start(key));
         }
         mx = wave_max(mx);
-        if (lane == 0 && mx > HIT_BOUND) s_fb = 1;
+        if (lane == 0 && mx > HIT_BOUND) s_exact = 1;
+        BAR_LDS();
+        if (UNI(s_exact)) {
+            const uint16_t* fh = reinterpret_cast<const uint16_t*>(farh);
+            mx = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int key = 2 * tid + k, cls = key / NBIN, bin = key % NBIN;
+                int sum = 0;
+                for (int d = 0; d < 18 && bin + d < NBIN; ++d) sum += fh[cls * NBIN + bin + d];
+                mx = max(mx, sum);
+            }
+            mx = wave_max(mx);
+            if (lane == 0 && mx > HIT_BOUND) s_fb = 1;
+        }
     }
     BAR_LDS();                                                                 // the window's first words become event counts next
     STAMP(1);
@@ -406,15 +418,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     uint32_t* const evn32 = cnt;                                                   // [npair] 16-bit event counts
     uint16_t* const evl = reinterpret_cast<uint16_t*>(cnt + npair / 2);            // [npair][ECAP] (beam << 3) | rank
     uint16_t* const spl = evl + npair * ECAP;                                      // [RSPEC] pairs that need the other classes
-    struct FCell { int sx, sy; int gxs[2], gys[2]; int ngx, ngy; };                // storage cell and its source global cells
+    struct FCell { int sx, sy; int gx0, gx1, gy0, gy1; int ngx, ngy; };            // storage cell and its source global cells (scalars: no indexed arrays)
     auto cell_sources = [&](uint32_t sc, FCell& f) {
         f.sx = (int)(sc >> 16); f.sy = (int)(sc & 0xFFFFu);
         const int ax = f.sx - C, ay = f.sy - C;                                     // sources: a (if not glitched), a + 1 (if glitched)
-        f.ngx = 0; f.ngy = 0;
-        if (!gxb[ax - fxl]) f.gxs[f.ngx++] = ax;
-        if (gxb[ax + 1 - fxl]) f.gxs[f.ngx++] = ax + 1;
-        if (!gyb[ay - fyl]) f.gys[f.ngy++] = ay;
-        if (gyb[ay + 1 - fyl]) f.gys[f.ngy++] = ay + 1;
+        const bool xa = !gxb[ax - fxl], xb = gxb[ax + 1 - fxl], ya = !gyb[ay - fyl], yb = gyb[ay + 1 - fyl];
+        f.ngx = (xa ? 1 : 0) + (xb ? 1 : 0); f.gx0 = xa ? ax : ax + 1; f.gx1 = ax + 1;
+        f.ngy = (ya ? 1 : 0) + (yb ? 1 : 0); f.gy0 = ya ? ay : ay + 1; f.gy1 = ay + 1;
     };
     auto old_value = [&](const FCell& f) {
         const int a = a0 + (f.sx >= (a0 + 1) * v.dim ? 1 : 0) - (f.sx < a0 * v.dim ? 1 : 0);   // rays are shorter than a tile
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     BAR_LDS();
     // the sorted order as packed records: one 8-byte read per candidate ray
     uint2* const srec = reinterpret_cast<uint2*>(spl + RSPEC);                     // [B] {slope | OCC << 24 | NEAR << 25, dmaj | beam << 16}
-    uint16_t* const alist = reinterpret_cast<uint16_t*>(srec + G.bpad);            // [B] beams with a cell in play
+    uint16_t* const alist = reinterpret_cast<uint16_t*>(srec + G.bpad);            // [2 * B] pairs in play
     for (int q = tid; q < UNI(bkt_end(8 * NBIN - 1)); q += RB) {
         const int rb = brays[q];
         rpos[rb] = (uint16_t)q;
@@ -478,12 +488,12 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     BAR_LDS();
     STAMP(2);
-    // ---- pass 1: one lane per beam scans its neighbours in slope order once, for its end cell and the cell before it ----
+    // ---- pass 1: one lane per pair scans its beam's neighbours in slope order ----
     // In the frame of the beam's class a storage cell's global source cells are the major steps {j1, j2} x the minor
     // offsets {c1, c2} (the second of each only where the index map repeats a cell); a ray of the class crosses the cell
     // iff minor(j) is c1 or c2 for one of those j it reaches.
-    // Beams with a cell in play, listed in the order of perm (rays by falling length): the lanes of a wave then scan
-    // windows of similar width (a window holds ~ 1/j of a class's rays), so that few lanes wait for a long scan.
+    // Pairs in play, listed in the order of perm (rays by falling length): the lanes of a wave then scan windows of
+    // similar width (a window holds ~ 1/j of a class's rays), so that few lanes wait for a long scan.
     {
         const int n1 = UNI(s_nk[1]);                                               // rays in perm; the shorter ones follow in beam order
         for (int i0 = 0; i0 < n1 + v.B; i0 += RB) {                                // wave-uniform trip count (ballot)
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             int b = -1;
             if (i < n1) b = perm[i];
             else if (i - n1 < v.B && ((int)r_dmaj[i - n1] + 1) / NEAR_R - 1 < 1) b = i - n1;
-            bool any = false;
+            bool play[2] = {false, false};
             if (b >= 0 && (r_info[b] & (RI_VALID | RI_OCC)) == (RI_VALID | RI_OCC)) {
                 for (int e = 0; e < 2; ++e) {
                     const uint32_t sc = scell[2 * b + e];
@@ -500,122 +510,120 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     bool dup = e == 1 && scell[2 * b] == sc;
                     if (b >= 1) dup = dup || scell[2 * b - 2] == sc || scell[2 * b - 1] == sc;
                     if (b >= 2) dup = dup || scell[2 * b - 4] == sc;
-                    if (!dup) { any = true; pflag[2 * b + e] = 3; }                  // 3 = in play, not classified yet
+                    if (!dup) { play[e] = true; pflag[2 * b + e] = 3; }              // 3 = in play, not classified yet
                 }
             }
-            const unsigned long long mask = __ballot(any);
+            const unsigned long long m0 = __ballot(play[0]), m1 = __ballot(play[1]);
             int base = 0;
-            if (lane == 0 && mask) base = atomicAdd(&s_nact, __popcll(mask));
+            if (lane == 0 && (m0 | m1)) base = atomicAdd(&s_nact, __popcll(m0) + __popcll(m1));
             base = __shfl(base, 0, 64);
-            if (any) alist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)b;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int pos = base + __popcll(m0 & lt) + __popcll(m1 & lt);
+            if (play[0]) alist[pos] = (uint16_t)(2 * b);
+            if (play[1]) alist[pos + (play[0] ? 1 : 0)] = (uint16_t)(2 * b + 1);
         }
     }
     BAR_LDS();
-    for (int it = tid; it < UNI(s_nact); it += RB) {                               // dense: (almost) every lane has a beam with work
-        const int b = alist[it];
-        const int info_b = r_info[b];
-        const int32_t re_b = r_end[b];
-        const int ex = (int)(int16_t)(re_b & 0xFFFF), ey = (int)(int16_t)((uint32_t)re_b >> 16);
-        const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
-        const int steep = aey > aex, dmaj_b = steep ? aey : aex;
-        const int smaj = steep ? (ey > 0 ? 1 : -1) : (ex > 0 ? 1 : -1), smin = steep ? (ex > 0 ? 1 : -1) : (ey > 0 ? 1 : -1);
-        const int cls = steep * 4 + (ex > 0 ? 2 : 0) + (ey > 0 ? 1 : 0);
-        const int cst = bkt_start(cls * NBIN), cen = bkt_end(cls * NBIN + NBIN - 1);
-        // the two cells: (storage cell, sources in the class frame, window on minor(dmaj_b), state)
-        int cj1[2], cj2[2], cc1[2], cc2[2], oldv[2], nev[2];
-        bool act[2];
-        int lo = INT_MAX, hi = -1;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t sc = scell[2 * b + e];
-            act[e] = pflag[2 * b + e] == 3;
-            nev[e] = 0; cj1[e] = cj2[e] = cc1[e] = cc2[e] = -1; oldv[e] = 0;
-            if (!act[e]) continue;
+    for (int it0 = 0; it0 < UNI(s_nact); it0 += RB) {                              // dense: (almost) every lane has a pair
+        const int it = it0 + tid;
+        const bool have = it < UNI(s_nact);
+        const int mykey = have ? (int)alist[it] : 0;
+        const int b = mykey >> 1;
+        int nev = 0, oldv = 0;
+        bool act = false;
+        if (have) {
+            const int32_t re_b = r_end[b];
+            const int ex = (int)(int16_t)(re_b & 0xFFFF), ey = (int)(int16_t)((uint32_t)re_b >> 16);
+            const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+            const int steep = aey > aex, dmaj_b = steep ? aey : aex;
+            const int smaj = steep ? (ey > 0 ? 1 : -1) : (ex > 0 ? 1 : -1), smin = steep ? (ex > 0 ? 1 : -1) : (ey > 0 ? 1 : -1);
+            const int cls = steep * 4 + (ex > 0 ? 2 : 0) + (ey > 0 ? 1 : 0);
+            const int cst = bkt_start(cls * NBIN), cen = bkt_end(cls * NBIN + NBIN - 1);
             FCell f;
-            cell_sources(sc, f);
-            oldv[e] = old_value(f);                                                // in flight during the scan
-            const int mykey = b << 1 | e;
-            bool near_cell = false, special = false;
+            cell_sources(scell[mykey], f);
+            oldv = old_value(f);                                                   // in flight during the scan
             // sources along the major and the minor axis of the class frame
-            const int* gmaj = steep ? f.gys : f.gxs; const int nmaj = steep ? f.ngy : f.ngx;
-            const int* gmin = steep ? f.gxs : f.gys; const int nmin = steep ? f.ngx : f.ngy;
+            const int gmaj0 = steep ? f.gy0 : f.gx0, gmaj1 = steep ? f.gy1 : f.gx1, nmaj = steep ? f.ngy : f.ngx;
+            const int gmin0 = steep ? f.gx0 : f.gy0, gmin1 = steep ? f.gx1 : f.gy1, nmin = steep ? f.ngx : f.ngy;
             const int omaj = steep ? y0 : x0, omin = steep ? x0 : y0;
-            cj1[e] = (gmaj[0] - omaj) * smaj; if (nmaj > 1) cj2[e] = (gmaj[1] - omaj) * smaj;
-            cc1[e] = (gmin[0] - omin) * smin; if (nmin > 1) cc2[e] = (gmin[1] - omin) * smin;
-            const int jmin = nmaj > 1 ? min(cj1[e], cj2[e]) : cj1[e], jmax = nmaj > 1 ? max(cj1[e], cj2[e]) : cj1[e];
-            const int cmin = nmin > 1 ? min(cc1[e], cc2[e]) : cc1[e], cmax = nmin > 1 ? max(cc1[e], cc2[e]) : cc1[e];
-            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
-                const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
+            const int cj1 = (gmaj0 - omaj) * smaj, cj2 = nmaj > 1 ? (gmaj1 - omaj) * smaj : -1;
+            const int cc1 = (gmin0 - omin) * smin, cc2 = nmin > 1 ? (gmin1 - omin) * smin : -1;
+            const int jmin = nmaj > 1 ? min(cj1, cj2) : cj1, jmax = nmaj > 1 ? max(cj1, cj2) : cj1;
+            const int cmin = nmin > 1 ? min(cc1, cc2) : cc1, cmax = nmin > 1 ? max(cc1, cc2) : cc1;
+            bool near_cell = false;
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+                if (ix >= f.ngx || iy >= f.ngy) continue;
+                const int sgx = ix ? f.gx1 : f.gx0, sgy = iy ? f.gy1 : f.gy0;
+                const int ddx = sgx - x0, ddy = sgy - y0;
                 if (max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy) < NEAR_R) near_cell = true;
             }
-            if (cmin <= 0 || cmax >= jmin) special = true;                           // an axis or a diagonal through the sensor: other classes reach it
-            if (near_cell) {   // most rays cross it: the wave-wide scan over all beams; claimed through bit 15 of the first source's 16-bit field
-                const int mi = (f.gxs[0] - x0 + NEAR_R) * NEAR_W + (f.gys[0] - y0 + NEAR_R), sh = (mi & 1) * 16;
+            const bool special = cmin <= 0 || cmax >= jmin;                         // an axis or a diagonal through the sensor: other classes reach it
+            if (near_cell) {   // most rays cross it: the scan over all beams; claimed through bit 15 of the first source's 16-bit field
+                const int mi = (f.gx0 - x0 + NEAR_R) * NEAR_W + (f.gy0 - y0 + NEAR_R), sh = (mi & 1) * 16;
                 if (!((atomicOr(&mini[mi >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
                     const int pos = atomicAdd(&s_nslow, 1);
                     if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
                 }
-                act[e] = false; pflag[mykey] = 0;
-                continue;
-            }
-            // window on minor(dmaj_b) of a ray that can reach a source: minor() never decreases and moves by at most one
-            // per major step, so minor(js) = cs needs minor(dmaj_b) in [cs, cs + (dmaj_b - js)] (js <= dmaj_b) or
-            // [cs - (js - dmaj_b), cs] (js > dmaj_b)
-            lo = min(lo, cmin - max(0, jmax - dmaj_b)); hi = max(hi, cmax + max(0, dmaj_b - jmin));
-            pflag[mykey] = special ? 2 : 1;
-            if (special) {
-                const int pos = atomicAdd(&s_nspec, 1);
-                if (pos < RSPEC) spl[pos] = (uint16_t)mykey; else s_fb = 1;
-            }
-        }
-        if (!act[0] && !act[1]) continue;
-        const int q0 = rpos[b];
-        for (int dir = 0; dir < 2; ++dir) {                                         // dir 0: b and the steeper slopes, dir 1: the flatter ones
-            for (int q = dir ? q0 - 1 : q0; dir ? q >= cst : q < cen; q += dir ? -1 : 1) {
-                const uint2 rr = srec[q];
-                const uint32_t fs = rr.x & 0xFFFFFFu;
-                const int dmaj_r = (int)(rr.y & 0xFFFFu), rb = (int)(rr.y >> 16);
-                const int mg = (int)((fs * (uint32_t)dmaj_b + (1u << (RFIX - 1))) >> RFIX);
-                if (dir ? mg < lo : mg > hi) break;                                 // sorted by slope: nothing further can reach a cell
+                pflag[mykey] = 0;
+            } else {
+                act = true;
+                // window on minor(dmaj_b) of a ray that can reach a source: minor() never decreases and moves by at most one
+                // per major step, so minor(js) = cs needs minor(dmaj_b) in [cs, cs + (dmaj_b - js)] (js <= dmaj_b) or
+                // [cs - (js - dmaj_b), cs] (js > dmaj_b)
+                const int lo = cmin - max(0, jmax - dmaj_b), hi = cmax + max(0, dmaj_b - jmin);
+                pflag[mykey] = special ? 2 : 1;
+                if (special) {
+                    const int pos = atomicAdd(&s_nspec, 1);
+                    if (pos < RSPEC) spl[pos] = (uint16_t)mykey; else s_fb = 1;
+                }
+                uint16_t* const myev = evl + mykey * ECAP;
+                const int q0 = rpos[b];
+                for (int dir = 0; dir < 2 && act; ++dir) {                          // dir 0: b and the steeper slopes, dir 1: the flatter ones
+                    for (int q = dir ? q0 - 1 : q0; dir ? q >= cst : q < cen; q += dir ? -1 : 1) {
+                        const uint2 rr = srec[q];
+                        const uint32_t fs = rr.x & 0xFFFFFFu;
+                        const int dmaj_r = (int)(rr.y & 0xFFFFu), rb = (int)(rr.y >> 16);
+                        const int mg = (int)((fs * (uint32_t)dmaj_b + (1u << (RFIX - 1))) >> RFIX);
+                        if (dir ? mg < lo : mg > hi) break;                         // sorted by slope: nothing further can reach the cell
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (!act[e]) continue;
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const int jj = w ? cj2[e] : cj1[e];
-                        if (jj < 0 || jj > dmaj_r) continue;
-                        const int m = (int)((fs * (uint32_t)jj + (1u << (RFIX - 1))) >> RFIX);
-                        if (m != cc1[e] && m != cc2[e]) continue;
-                        const int rem = dmaj_r - jj;
-                        const bool occ_r = (rr.x >> 24) & 1u, nearev = rem == 1 && ((rr.x >> 25) & 1u);
-                        const int rank = rem == 0 ? (occ_r ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
-                        const int mykey = b << 1 | e;
-                        if ((rank == EV_OCC && (rb << 1) < mykey) || (nearev && (rb << 1 | 1) < mykey)) { act[e] = false; break; }
-                        uint16_t* const myev = evl + mykey * ECAP;
-                        if (nev[e] < ECAP) myev[nev[e]] = (uint16_t)(rb << 3 | rank);
-                        ++nev[e];
-                        if (nearev) { if (nev[e] < ECAP) myev[nev[e]] = (uint16_t)(rb << 3 | EV_NEAR); ++nev[e]; }
+                        for (int w = 0; w < 2; ++w) {
+                            const int jj = w ? cj2 : cj1;
+                            if (jj < 0 || jj > dmaj_r) continue;
+                            const int m = (int)((fs * (uint32_t)jj + (1u << (RFIX - 1))) >> RFIX);
+                            if (m != cc1 && m != cc2) continue;
+                            const int rem = dmaj_r - jj;
+                            const bool occ_r = (rr.x >> 24) & 1u, nearev = rem == 1 && ((rr.x >> 25) & 1u);
+                            const int rank = rem == 0 ? (occ_r ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+                            if ((rank == EV_OCC && (rb << 1) < mykey) || (nearev && (rb << 1 | 1) < mykey)) { act = false; break; }
+                            if (nev < ECAP) myev[nev] = (uint16_t)(rb << 3 | rank);
+                            ++nev;
+                            if (nearev) { if (nev < ECAP) myev[nev] = (uint16_t)(rb << 3 | EV_NEAR); ++nev; }
+                        }
+                        if (!act) break;
                     }
                 }
-                if (!act[0] && !act[1]) break;
+                if (!act) pflag[mykey] = 0;
             }
         }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (!act[e]) { if (pflag[b << 1 | e]) pflag[b << 1 | e] = 0; continue; }
-            const int mykey = b << 1 | e;
-            oldv8[mykey] = (uint8_t)oldv[e];
+        // finalize: the network that fits the longest list of the wave
+        bool fin = false;
+        if (act) {
+            oldv8[mykey] = (uint8_t)oldv;
             if (pflag[mykey] == 2) {                                               // the other classes add their events in pass 2
-                atomicAdd(&evn32[mykey >> 1], (uint32_t)nev[e] << ((mykey & 1) * 16));
-                continue;
-            }
-            if (nev[e] > ECAP) {
+                atomicAdd(&evn32[mykey >> 1], (uint32_t)nev << ((mykey & 1) * 16));
+            } else if (nev > ECAP) {
                 const int pos = atomicAdd(&s_nslow, 1);
                 if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
-                continue;
-            }
+            } else fin = true;
+        }
+        const int nmax = wave_max(fin ? nev : 0);
+        if (fin) {
             const uint16_t* myev = evl + mykey * ECAP;
-            const int val = nev[e] <= 8 ? replay_sorted<8>(myev, nev[e], oldv[e], v.cc) : replay_sorted<ECAP>(myev, nev[e], oldv[e], v.cc);
+            const int val = nmax <= 4 ? replay_sorted<4>(myev, nev, oldv, v.cc) : nmax <= 8 ? replay_sorted<8>(myev, nev, oldv, v.cc)
+                                                                                            : replay_sorted<ECAP>(myev, nev, oldv, v.cc);
             oval[mykey] = (uint8_t)(val - v.cc.vmin);
         }
     }
@@ -634,8 +642,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             // slope buckets of this class that can hold a ray through one of the sources
             const int steep = cls >> 2, smaj = steep ? ((cls & 1) ? 1 : -1) : ((cls & 2) ? 1 : -1), smin = steep ? ((cls & 2) ? 1 : -1) : ((cls & 1) ? 1 : -1);
             int blo = NBIN, bhi = -1;
-            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
-                const int ddx = f.gxs[ix] - x0, ddy = f.gys[iy] - y0;
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+                if (ix >= f.ngx || iy >= f.ngy) continue;
+                const int sgx = ix ? f.gx1 : f.gx0, sgy = iy ? f.gy1 : f.gy0;
+                const int ddx = sgx - x0, ddy = sgy - y0;
                 const int j = (steep ? ddy : ddx) * smaj, c = (steep ? ddx : ddy) * smin;
                 if (j <= 0 || c < 0 || c > j) continue;
                 const float inv = (float)NBIN / (float)j;
@@ -648,9 +661,14 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const int rb = brays[q];
                 RayP r;
                 load_ray(rb, r);
-                for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy) {
+                    if (ix >= f.ngx || iy >= f.ngy) continue;
+                    const int sgx = ix ? f.gx1 : f.gx0, sgy = iy ? f.gy1 : f.gy0;
                     int rank; bool nearev;
-                    if (!ray_hits(r, f.gxs[ix] - x0, f.gys[iy] - y0, rank, nearev)) continue;
+                    if (!ray_hits(r, sgx - x0, sgy - y0, rank, nearev)) continue;
                     int pos = (int)((atomicAdd(&evn32[pair >> 1], 1u << psh) >> psh) & 0xFFFFu);
                     if (pos < ECAP) evl[pair * ECAP + pos] = (uint16_t)(rb << 3 | rank);
                     if (nearev) {
@@ -684,14 +702,55 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     BAR_LDS();
     if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW || UNI(s_nspec) > RSPEC ? 3 : 2); }
-    {   // cells near the sensor and cells with more than ECAP events: one wave each, exact membership test over all beams
+    {   // cells near the sensor and cells with more than ECAP events: exact membership test over all beams, one cell at a
+        // time by the whole workgroup.  A lane folds the events of its beam (the clamped adds compose associatively: Caf),
+        // a wave folds its 64 consecutive beams with a shuffle tree, thread 0 folds the waves' results in beam order.
         const int nslow = UNI(s_nslow);
-        for (int k = wave; k < nslow; k += RB / 64) {
-            const int key = slowl[k];
+        int* const s_caf = reinterpret_cast<int*>(cnt);                            // [chunks of 64 beams][3] (the event lists are done with)
+        const int BIG = 1000000;
+        const Caf fE = {v.cc.emp, v.cc.vmin, BIG}, fO = {v.cc.occ, -BIG, v.cc.vmax}, fN = {v.cc.nearby, -BIG, v.cc.vmax};
+        for (int k = 0; k < nslow; ++k) {
+            const int key = UNI(slowl[k]);
             FCell f;
             cell_sources(scell[key], f);
-            const int val = replay_cell_wave(v, r_info, r_end, x0, y0, f.gxs, f.ngx, f.gys, f.ngy, old_value(f), lane);
-            if (lane == 0) oval[key] = (uint8_t)(val - v.cc.vmin);
+            const int val0 = tid == 0 ? old_value(f) : 0;
+            for (int base = 0; base < v.B; base += RB) {
+                const int b = base + tid;
+                Caf fb = {0, -BIG, BIG};
+                if (b < v.B && (r_info[b] & RI_VALID)) {
+                    RayP r;
+                    load_ray(b, r);
+                    bool occ_ev = false, near_ev = false;
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy) {
+                        if (ix >= f.ngx || iy >= f.ngy) continue;
+                        const int sgx = ix ? f.gx1 : f.gx0, sgy = iy ? f.gy1 : f.gy0;
+                        int rank; bool ne;
+                        if (!ray_hits(r, sgx - x0, sgy - y0, rank, ne)) continue;
+                        if (rank == EV_OCC) occ_ev = true; else fb = caf_then(fb, fE);   // the beam's passes come before its last step
+                        near_ev = near_ev || ne;
+                    }
+                    if (occ_ev) fb = caf_then(fb, fO);
+                    if (near_ev) fb = caf_then(fb, fN);
+                }
+                if (base + 64 * wave < v.B) {                                      // (wave-uniform)
+                    for (int off = 1; off < 64; off <<= 1) {
+                        Caf g;
+                        g.a = __shfl_down(fb.a, off, 64); g.lo = __shfl_down(fb.lo, off, 64); g.hi = __shfl_down(fb.hi, off, 64);
+                        if ((lane & (2 * off - 1)) == 0) fb = caf_then(fb, g);
+                    }
+                    if (lane == 0) { int* o = s_caf + 3 * ((base >> 6) + wave); o[0] = fb.a; o[1] = fb.lo; o[2] = fb.hi; }
+                }
+            }
+            BAR_LDS();
+            if (tid == 0) {
+                int val = val0;
+                for (int c = 0; c < (v.B + 63) >> 6; ++c) { const Caf g = {s_caf[3 * c], s_caf[3 * c + 1], s_caf[3 * c + 2]}; val = caf_apply(g, val); }
+                oval[key] = (uint8_t)(val - v.cc.vmin);
+            }
+            BAR_LDS();
         }
         if (tid == 0 && nslow) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)nslow);
     }
@@ -738,7 +797,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
 #pragma unroll
                     for (int u = 0; u < NEAR_R; ++u) {
                         const int c = aj + __mul24((int)(facc >> RFIX), mm);
-                        if (u <= dmaj) atomicAdd(&mini[c >> 1], 1u << ((c & 1) * 16));
+                        atomicAdd(&mini[c >> 1], u <= dmaj ? 1u << ((c & 1) * 16) : 0u);      // (a step past the end stays inside the block: adds nothing)
                         facc += fs; aj += mj;
                     }
                 }
@@ -772,8 +831,9 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
 #pragma unroll
                     for (int u = 0; u < NEAR_R; ++u) {
                         const int m = (int)(facc >> RFIX);
-                        const int c = aj + __mul24(m, cm);
-                        if ((unsigned)(rowj + m * rm) < (unsigned)rows_w) atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+                        const bool in = (unsigned)(rowj + m * rm) < (unsigned)rows_w;
+                        const int c = in ? aj + __mul24(m, cm) : 4 * lane;                 // outside the strip: nothing added, a word of the lane's own
+                        atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
                         facc += fs; aj += cj; rowj += rj;
                     }
                 }
@@ -792,12 +852,23 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 int aj = base0 + __mul24(j0, cj);
                 int rowj = rx0 + j0 * rj;
                 const int left = dmaj - j0;
+                if (whole) {
 #pragma unroll
-                for (int u = 0; u < NEAR_R - 1; ++u) {
-                    const int m = (int)(facc >> RFIX);
-                    const int c = aj + __mul24(m, cm);
-                    if (u <= left && (whole || (unsigned)(rowj + m * rm) < (unsigned)rows_w)) atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
-                    facc += fs; aj += cj; rowj += rj;
+                    for (int u = 0; u < NEAR_R - 1; ++u) {                         // branch-free: a dead step adds nothing to a word of the lane's own
+                        const bool in = u <= left;
+                        const int c = in ? aj + __mul24((int)(facc >> RFIX), cm) : 4 * lane;
+                        atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
+                        facc += fs; aj += cj;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NEAR_R - 1; ++u) {
+                        const int m = (int)(facc >> RFIX);
+                        const bool in = u <= left && (unsigned)(rowj + m * rm) < (unsigned)rows_w;
+                        const int c = in ? aj + __mul24(m, cm) : 4 * lane;
+                        atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
+                        facc += fs; aj += cj; rowj += rj;
+                    }
                 }
             }
         }
@@ -818,8 +889,14 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             FCell f;
             cell_sources(scell[pr], f);
             if (f.sx < S0 || f.sx > S1) continue;
-            for (int ix = 0; ix < f.ngx; ++ix) for (int iy = 0; iy < f.ngy; ++iy)
-                cnt8[(f.gxs[ix] - gx_base) * stride + (f.gys[iy] - gy_base)] = (ix | iy) ? (uint8_t)0 : (uint8_t)(0x80u | ov);
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+                if (ix >= f.ngx || iy >= f.ngy) continue;
+                const int sgx = ix ? f.gx1 : f.gx0, sgy = iy ? f.gy1 : f.gy0;
+                cnt8[(sgx - gx_base) * stride + (sgy - gy_base)] = (ix | iy) ? (uint8_t)0 : (uint8_t)(0x80u | ov);
+            }
         }
         BAR_LDS();
         STAMP(6);
