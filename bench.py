@@ -328,7 +328,7 @@ def main():
                 "step_frac": step_ach / (HBM_PEAK_GBS * world),
                 "step_bytes_per_particle_update": bytes_pu,
                 "window_fallbacks_per_particle_step": c["window_fallbacks"] / n_fb,
-                "fan_kernel_give_backs_per_particle_step": sum((int(c["fallback_reasons"]) >> (16 * i)) & 0xFFFF for i in range(4)) / n_fb,
+                "fast_kernel_give_backs_per_particle_step": sum((int(c["fallback_reasons"]) >> (16 * i)) & 0xFFFF for i in range(4)) / n_fb,
                 "global_index_kernel_windows_per_particle_step": c["map_windows"] / n_fb,
                 "algorithmic_bytes_per_particle_update": alg_bytes[dominant],
                 "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,

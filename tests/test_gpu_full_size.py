@@ -81,7 +81,7 @@ def _run_config(P, B, cs, fov, steps_checked, steps_total, probe):
     ms = e.kernel_ms("raycast")
     out = {"particles": P, "beams": B, "cell_size": cs, "steps": n,
            "window_fallbacks_per_particle_step": c["window_fallbacks"] / (P * n),
-           "fan_kernel_give_backs_per_particle_step": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / (P * n),
+           "fast_kernel_give_backs_per_particle_step": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / (P * n),
            "ray_kernel_windows_per_particle_step": c["map_windows"] / (P * n),
            "tiles_in_use": c["tiles_in_use"], "map_update_ms_mean": float(ms[1:].mean()) if len(ms) > 1 else None,
            "median_position_error_m": float(err)}
@@ -106,9 +106,9 @@ def test_config5_share_8192_particles_181_beams_0025m():
 
 @pytest.mark.parametrize("cs", [0.05, 0.1])
 def test_intel_head_fallback_fraction(cs):
-    """The first 70 scans of data/intel.txt through the reference's loop: how many particle-updates leave the whole-fan
-    kernel (rays up to the 15 m cap of hybridmap.py:107 make fans of up to 600 cells at 0.05 m) and how many reach the
-    128x128-window kernel at the end of the chain (none)."""
+    """The first 70 scans of data/intel.txt through the reference's loop (rays up to the 15 m cap of hybridmap.py:107 make
+    fans of up to 600 cells at 0.05 m): how many particle-updates the global-index kernel hands to the 128x128-window
+    kernel (none), and how many strips it needs."""
     from thesis_amd.datasets.carmen import load_carmen
     from thesis_amd.slam import ParticleFilter, run_log
     log = load_carmen(os.path.join(HERE, "golden", "intel_head.log"))
@@ -119,7 +119,7 @@ def test_intel_head_fallback_fraction(cs):
     n = 64 * max(1, c["scan_updates"])
     out = {"accepted_scans": res.accepted, "map_updates": c["scan_updates"],
            "window_fallbacks_per_particle_update": c["window_fallbacks"] / n,
-           "fan_kernel_give_backs_per_particle_update": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / n,
+           "fast_kernel_give_backs_per_particle_update": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / n,
            "ray_kernel_windows_per_particle_update": c["map_windows"] / n}
     _report(f"intel_head cs={cs}", out)
     pf.close()
@@ -127,11 +127,12 @@ def test_intel_head_fallback_fraction(cs):
         assert out["window_fallbacks_per_particle_update"] <= 0.02
 
 
-def test_fans_too_large_for_the_whole_fan_kernel_go_to_the_global_index_kernel():
-    """15 m rays all round at 0.05 m: 600-cell fans, twice the whole-fan kernel's window.  The first launch finds that out
-    per particle after its setup; from the second launch on the kernel leaves the particles to the global-index kernel
-    at once (every 16th still tries: `mu_hint`).  Cell-exact against the C oracle for a few particles, no particle
-    reaches the 128x128-window kernel."""
+def test_fans_too_large_for_the_whole_fan_kernel_go_to_the_global_index_kernel(monkeypatch):
+    """15 m rays all round at 0.05 m: 600-cell fans, twice the whole-fan kernel's window, with all three kernels in a row
+    (RBPF_MAP_KERNEL=chain).  The first launch finds that out per particle after its setup; from the second launch on the
+    whole-fan kernel leaves the particles to the global-index kernel at once (every 16th still tries: `mu_hint`).
+    Cell-exact against the C oracle for a few particles, no particle reaches the 128x128-window kernel."""
+    monkeypatch.setenv("RBPF_MAP_KERNEL", "chain")
     from thesis_amd.engine import ParticleEngine
     P, B = 96, 721
     ang = np.linspace(-np.pi, np.pi, B, endpoint=False)

@@ -18,17 +18,18 @@ def eng_mod():
 
 
 def select_map_kernel(monkeypatch, name):
-    """"auto" = the default chain (whole-fan kernel, then the global-index kernel, then windows); "ray" / "fan" / "window"
-    run only that kernel (and windows for what it gives back), through RBPF_MAP_KERNEL, which rbpf_create reads."""
+    """"auto" = the default chain (global-index kernel, then windows for what it gives back); "chain" = whole-fan kernel,
+    global-index kernel, windows in a row; "ray" / "fan" / "window" run only that kernel (and windows for what it gives
+    back), through RBPF_MAP_KERNEL, which rbpf_create reads."""
     if name == "auto":
         monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
     else:
         monkeypatch.setenv("RBPF_MAP_KERNEL", name)
 
 
-@pytest.fixture(params=["auto", "ray", "fan", "window"])
+@pytest.fixture(params=["auto", "chain", "fan", "window"])
 def map_kernel(request, monkeypatch):
-    """The default chain and each of the three map-update kernels on its own."""
+    """The default chain (= the global-index kernel first), all three kernels in a row, the whole-fan and the window kernel on their own."""
     select_map_kernel(monkeypatch, request.param)
     return request.param
 
@@ -142,7 +143,7 @@ def test_map_update_random_particles_vs_oracle(eng_mod, map_kernel):
     e.close()
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ray", "fan"])
+@pytest.mark.parametrize("kernel", ["auto", "chain", "fan"])
 @pytest.mark.parametrize("scene", ["near_wall", "one_direction", "tile_corner", "negative_side", "short_rays"])
 def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
     """Inputs chosen against the whole-fan kernel's layout limits: cells hit by more rays than an 8-bit field may
@@ -512,7 +513,7 @@ def test_map_update_on_a_lattice_line_known_deviation(eng_mod):
         e.close()
 
 
-@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "auto"), (0.1, 180, "window"), (0.05, 721, "fan"), (0.025, 181, "ray"), (0.1, 180, "auto"), (0.05, 361, "ray")])
+@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "auto"), (0.1, 180, "window"), (0.05, 721, "fan"), (0.025, 181, "ray"), (0.1, 180, "chain"), (0.05, 361, "auto")])
 def test_closed_loop_population_equals_oracle(eng_mod, monkeypatch, cs, B, kernel):
     """(Cell sizes of configs C1, C2 and C5, both map-update kernels.)  The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
     IMU propagation, Robot.map_update with the engine seam doubled (matcher result and proposal samples injected on both

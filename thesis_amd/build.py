@@ -50,7 +50,7 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
         fresh = os.path.exists(obj) and not any(_newer(d, os.path.getmtime(obj)) for d in [path] + common)
         if fresh and not force and not stamped and not os.path.exists(obj + ".stamped"):
             continue
-        extra = ["-DRBPF_STAMPS"] if stamped else []
+        extra = (["-DRBPF_STAMPS"] + os.environ.get("RBPF_STAMP_DEFS", "").split()) if stamped else []   # e.g. RBPF_STAMP_DEFS="-DABLATE=1"
         jobs.append(([hipcc, *FLAGS, *extra, "-c", path, "-o", obj], obj, stamped))
 
     def run(job):

@@ -21,7 +21,7 @@
 //     before anything is written, so every table overflow still hands the particle back untouched.
 //   * A fan larger than the LDS window is processed in strips of storage rows (one launch, any fan size): cell sizes
 //     of 0.025 m and 15 m rays included.  8-bit counters cannot overflow: a bound on the hits of any cell with j >= 16
-//     is checked from the slope buckets first (cells nearer than 16 steps live in a 16-bit block).
+//     is checked from the slope buckets first (cells nearer than NEAR_R steps live in a 16-bit block).
 #include "rbpf_mapupdate.h"
 
 namespace rbpf {
@@ -38,19 +38,25 @@ namespace rbpf {
 
 static const int RB = 1024;                    // threads per particle
 static const int NEAR_R = 16;                  // ray steps j < NEAR_R are counted in the 16-bit block
+static const int LCH = 16;                     // steps per chunk of the walk beyond it
 static const int NEAR_W = 2 * NEAR_R + 1;      // cells with Chebyshev distance <= NEAR_R from the start cell (one spare ring)
 static const int NBIN = 256;                   // slope buckets per direction class
 static const int RFIX = 22;                    // fixed-point bits of the slope (fix_slope)
 static const int BIN_SHIFT = RFIX - 8;
 static const int RSLOW = 256;                  // flagged cells replayed by the wave-wide exact scan, per particle
 static const int ECAP = 16;                    // events per flagged cell kept in its list (more: the wave-wide scan)
+static const int NNEAR = 128;                  // flagged cells inside the 16-bit block that collect their events from the block's walk
+static const int NSPC = 32;                    // occupied / nearby events of such a cell
+static const int NPOOL = 48;                   // flagged cells with more than ECAP events: lists of PCAP events, sorted and folded by a wave
+static const int PCAP = 64;
 static const int RSPEC = 512;                  // flagged cells on an axis or a diagonal through the sensor, per particle
 static const int MAXLEV = 63;                  // whole 16-step chunks per ray (reach < 1000 cells)
+static const int NB_WIN = NBIN / NEAR_R + 2;   // slope buckets that can hold the rays through one cell beyond the 16-bit block
 static const int HIT_BOUND = 63;               // per direction class; two classes can meet in one cell: 126 < 128
 
 struct RayGeom {
     int fanw, bpad, ncell;
-    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_scell, o_oldv, o_rcc, o_rdmaj, o_perm, o_rpos, o_pflag;
+    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_scell, o_oldv, o_rcc, o_rdmaj, o_perm, o_rpos, o_pflag, o_nid, o_nearl;
     int bytes;
     bool ok;
 };
@@ -82,6 +88,8 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
     g.o_perm = o;  o += ray_al16(g.bpad * 2);
     g.o_rpos = o;  o += ray_al16(g.bpad * 2);
     g.o_pflag = o; o += ray_al16(g.bpad * 2);
+    g.o_nid = o;   o += ray_al16(NEAR_W * NEAR_W);
+    g.o_nearl = o; o += NNEAR * 2;
     g.o_cnt = o;
     const int avail = 160 * 1024 - 2048 - o - 64;      // 2 KB for the kernel's static LDS
     g.ncell = avail > 0 ? avail & ~127 : 0;
@@ -93,7 +101,7 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
 // the flagged-cell pass borrows the counter window: 16-bit event counts, ECAP events per pair, the special list
 __host__ __device__ inline bool ray_lists_fit(const RayGeom& g) {
     const int npair = 2 * g.bpad;
-    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + npair * 2 <= g.ncell;    // + the sorted ray records and the list of pairs in play
+    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + npair * 2 + NPOOL * (PCAP * 2 + 4) + 64 <= g.ncell;   // + the sorted ray records, the list of pairs in play, the long lists
 }
 
 bool map_update_ray_available(const DevView& v) {
@@ -145,13 +153,15 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     uint16_t* const r_dmaj = reinterpret_cast<uint16_t*>(smem + G.o_rdmaj); // [B] last step of the ray
     uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole 16-step chunks
     uint16_t* const rpos = reinterpret_cast<uint16_t*>(smem + G.o_rpos);   // [B] position of the ray in brays
+    uint8_t*  const nid = smem + G.o_nid;                                  // [NEAR_W^2] list position of the flagged cell a block cell is a source of, 0xFF = none
+    uint16_t* const nearl = reinterpret_cast<uint16_t*>(smem + G.o_nearl); // [NNEAR] owner pairs of those cells
     uint8_t*  const pflag = smem + G.o_pflag;                              // [2 * B] 0 = pair not in play, 1 = gathered, 2 = other classes too
 
     __shared__ int s_fb;
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];
     __shared__ int s_wsum[RB / 64];
-    __shared__ int s_nslow, s_written, s_nspec, s_nact, s_exact;
+    __shared__ int s_nslow, s_written, s_nspec, s_nact, s_exact, s_nnear, s_npool;
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
 
@@ -193,12 +203,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     if (tid == 0) {
         s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
-        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_nact = 0; s_exact = 0;
+        s_cells = 0; s_fb = 0; s_written = 0; s_nslow = 0; s_nspec = 0; s_nact = 0; s_exact = 0; s_nnear = 0; s_npool = 0;
     }
     for (int i = tid; i < LL; i += RB) { s_need[i] = 0; s_tab[i] = tab[i]; }
     bins32[tid] = 0;
     if (tid <= MAXLEV) s_lcnt[tid] = 0;
     for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += RB) mini[i] = 0;
+    for (int i = tid; i < (NEAR_W * NEAR_W + 3) / 4; i += RB) reinterpret_cast<uint32_t*>(nid)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < (2 * G.bpad + 3) / 4; i += RB) reinterpret_cast<uint32_t*>(oval)[i] = 0xFFFFFFFFu;
     __syncthreads();
     STAMP(0);
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 fstep = ray_fix_slope(r.dmin, r.dmaj);
                 const int key = ray_key(ddx, ddy, fstep);
                 atomicAdd(&bins32[key >> 1], 1u << ((key & 1) * 16));
-                const int nfull = (r.dmaj + 1) / NEAR_R - 1;                         // whole chunks after level 0
+                const int nfull = (r.dmaj + 1 - NEAR_R) / LCH;                       // whole chunks beyond the 16-bit block
                 if (nfull >= 1) atomicAdd(&s_lcnt[min(nfull, MAXLEV)], 1);
             }
             r_dmaj[b] = (uint16_t)(r.n > 0 ? r.dmaj : 0);
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
         const int cj = aey > aex ? sy1 : sxs, cm = aey > aex ? sxs : sy1;
         r_cc[b] = ((uint32_t)cj & 0xFFFFu) | ((uint32_t)cm << 16);
-        const int nfull = ((int)r_dmaj[b] + 1) / NEAR_R - 1;
+        const int nfull = ((int)r_dmaj[b] + 1 - NEAR_R) / LCH;
         if (nfull >= 1) perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
         if ((int)r_dmaj[b] >= NEAR_R) atomicAdd(&farh[key >> 1], 1u << sh);            // only these reach the 8-bit fields
     }
@@ -376,14 +387,14 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     auto bkt_start = [&](int key) { return key ? (int)bins16[key - 1] : 0; };
     auto bkt_end = [&](int key) { return (int)bins16[key]; };
     {   // no 8-bit field can overflow: a cell at major distance j >= NEAR_R is hit, per direction class, only by rays
-        // that are at least that long and whose slope lies in a window of width 2^RFIX / j + 1 <= 2^18 + 1, i.e. in at most
-        // 18 consecutive buckets.  First with all rays of the buckets (two reads of the fill pointers); only when that
+        // that are at least that long and whose slope lies in a window of width 2^RFIX / j + 1 <= 2^RFIX / NEAR_R + 1, i.e. in
+        // at most NB_WIN consecutive buckets.  First with all rays of the buckets (two reads of the fill pointers); only when that
         // bound fails, with the rays that are long enough to reach an 8-bit field.
         int mx = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int key = 2 * tid + k, cls = key / NBIN, bin = key % NBIN;
-            mx = max(mx, bkt_end(cls * NBIN + min(bin + 17, NBIN - 1)) - bkt_start(key));
+            mx = max(mx, bkt_end(cls * NBIN + min(bin + NB_WIN - 1, NBIN - 1)) - bkt_start(key));
         }
         mx = wave_max(mx);
         if (lane == 0 && mx > HIT_BOUND) s_exact = 1;
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             for (int k = 0; k < 2; ++k) {
                 const int key = 2 * tid + k, cls = key / NBIN, bin = key % NBIN;
                 int sum = 0;
-                for (int d = 0; d < 18 && bin + d < NBIN; ++d) sum += fh[cls * NBIN + bin + d];
+                for (int d = 0; d < NB_WIN && bin + d < NBIN; ++d) sum += fh[cls * NBIN + bin + d];
                 mx = max(mx, sum);
             }
             mx = wave_max(mx);
@@ -453,12 +464,56 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         nearev = rem == 1 && (r.info & RI_NEAR);
         return true;
     };
-    {   // order the rays of every bucket by slope (ties by beam): the class is then sorted as a whole; rpos = inverse
+    // ---- the 16-bit block: steps 0 .. NEAR_R - 1 of every ray (it outlives the windows) ----
+    auto walk_block = [&](bool collect, int* ncur, const int* nend, uint16_t* nev) {
+        const int nw0 = (v.B + 63) >> 6;
+        for (int q = wave; q < nw0; q += RB / 64) {
+            const int b = lane * nw0 + q;                                          // the 64 rays of an instruction point in different directions
+            if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
+            const uint32_t fs = r_fstep[b];
+            const uint32_t cc = r_cc[b];
+            const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+            const int dmaj = (int)r_dmaj[b];
+            const int mj = cj == 1 || cj == -1 ? cj : (cj > 0 ? NEAR_W : -NEAR_W);   // the same steps in the 16-bit block
+            const int mm = cm == 1 || cm == -1 ? cm : (cm > 0 ? NEAR_W : -NEAR_W);
+            uint32_t facc = 1u << (RFIX - 1);
+            int aj = NEAR_R * NEAR_W + NEAR_R;
+            if (!collect) {
+#pragma unroll
+                for (int u = 0; u < NEAR_R; ++u) {
+                    const int c = aj + __mul24((int)(facc >> RFIX), mm);
+                    atomicAdd(&mini[c >> 1], u <= dmaj ? 1u << ((c & 1) * 16) : 0u);      // (a step past the end stays inside the block: adds nothing)
+                    facc += fs; aj += mj;
+                }
+            } else {
+                const int info = r_info[b];
+#pragma unroll
+                for (int u = 0; u < NEAR_R; ++u) {
+                    const int c = aj + __mul24((int)(facc >> RFIX), mm);
+                    const int id = nid[c];
+                    if (id != 0xFF && u <= dmaj) {                                     // rare: a source of a flagged cell
+                        const int rem = dmaj - u;
+                        const bool nearev = rem == 1 && (info & RI_NEAR);
+                        const int rank = rem == 0 ? ((info & RI_OCC) ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+                        const int pos = atomicAdd(&ncur[id], nearev ? 2 : 1);
+                        if (pos < nend[id]) nev[pos] = (uint16_t)(b << 3 | rank);
+                        if (nearev && pos + 1 < nend[id]) nev[pos + 1] = (uint16_t)(b << 3 | EV_NEAR);
+                    }
+                    facc += fs; aj += mj;
+                }
+            }
+        }
+    };
+    walk_block(false, nullptr, nullptr, nullptr);                                  // (no barrier: the waves go on to the bucket sort, whose threads mostly idle)
+    {   // order the rays of every bucket by slope (ties by beam): the class is then sorted as a whole; rpos = inverse.
+        // A regular scan has one or two rays per bucket (a thread sorts them in place); rays that end on a near surface
+        // share end cells, hence slopes: buckets of a dozen or more are ranked by a wave.
+        uint16_t* const bigb = evl + npair * ECAP;                                   // (the special list's place: not in use yet)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int key = 2 * tid + k, st = bkt_start(key), en = bkt_end(key);
-            if (en - st > 64) s_fb = 1;                                             // (a regular scan has one or two rays per bucket; rays that end on a
-                                                                                    // near surface share end cells, hence slopes: a dozen or two)
+            if (en - st > 64) s_fb = 1;
+            else if (en - st > 6) { const int pos = atomicAdd(&s_nspec, 1); if (pos < RSPEC) bigb[pos] = (uint16_t)key; else s_fb = 1; }
             else for (int i = st + 1; i < en; ++i) {
                 const int rb = brays[i];
                 const uint32_t fbase = (uint32_t)(key % NBIN) << BIN_SHIFT;          // slopes of a bucket differ in their low 14 (15 in the last) bits
@@ -474,11 +529,25 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         }
         for (int i = tid; i < npair / 2; i += RB) evn32[i] = 0;
         for (int i = tid; i < npair / 4; i += RB) reinterpret_cast<uint32_t*>(pflag)[i] = 0;
+        BAR_LDS();
+        const int nbig = UNI(min(s_nspec, RSPEC));
+        for (int k = wave; k < nbig; k += RB / 64) {
+            const int key = bigb[k], st = bkt_start(key), n = bkt_end(key) - st;   // 7 .. 64 rays
+            const uint32_t fbase = (uint32_t)(key % NBIN) << BIN_SHIFT;
+            const int rb = lane < n ? (int)brays[st + lane] : 0;
+            const uint32_t kf = lane < n ? ((r_fstep[rb] - fbase) << 12) | (uint32_t)rb : 0xFFFFFFFFu;
+            int rank = 0;
+            for (int e = 0; e < n; ++e) rank += (uint32_t)__shfl((int)kf, e, 64) < kf;          // keys are distinct (the beam is part of them)
+            if (lane < n) brays[st + rank] = (uint16_t)rb;                           // (every lane has read its own entry)
+        }
+        BAR_LDS();
+        if (tid == 0) s_nspec = 0;
     }
-    BAR_LDS();
     // the sorted order as packed records: one 8-byte read per candidate ray
     uint2* const srec = reinterpret_cast<uint2*>(spl + RSPEC);                     // [B] {slope | OCC << 24 | NEAR << 25, dmaj | beam << 16}
     uint16_t* const alist = reinterpret_cast<uint16_t*>(srec + G.bpad);            // [2 * B] pairs in play
+    uint32_t* const poolkey = reinterpret_cast<uint32_t*>(alist + ((npair + 7) & ~7));   // [NPOOL] pair | events << 16 of a long list, ~0 = abandoned
+    uint16_t* const pool = reinterpret_cast<uint16_t*>(poolkey + NPOOL);           // [NPOOL][PCAP]
     for (int q = tid; q < UNI(bkt_end(8 * NBIN - 1)); q += RB) {
         const int rb = brays[q];
         rpos[rb] = (uint16_t)q;
@@ -500,7 +569,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const int i = i0 + tid;
             int b = -1;
             if (i < n1) b = perm[i];
-            else if (i - n1 < v.B && ((int)r_dmaj[i - n1] + 1) / NEAR_R - 1 < 1) b = i - n1;
+            else if (i - n1 < v.B && ((int)r_dmaj[i - n1] + 1 - NEAR_R) / LCH < 1) b = i - n1;
             bool play[2] = {false, false};
             if (b >= 0 && (r_info[b] & (RI_VALID | RI_OCC)) == (RI_VALID | RI_OCC)) {
                 for (int e = 0; e < 2; ++e) {
@@ -529,7 +598,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         const bool have = it < UNI(s_nact);
         const int mykey = have ? (int)alist[it] : 0;
         const int b = mykey >> 1;
-        int nev = 0, oldv = 0;
+        int nev = 0, oldv = 0, cap = ECAP, slot = -1;
         bool act = false;
         if (have) {
             const int32_t re_b = r_end[b];
@@ -561,11 +630,34 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 if (max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy) < NEAR_R) near_cell = true;
             }
             const bool special = cmin <= 0 || cmax >= jmin;                         // an axis or a diagonal through the sensor: other classes reach it
-            if (near_cell) {   // most rays cross it: the scan over all beams; claimed through bit 15 of the first source's 16-bit field
+            if (near_cell) {   // most rays cross it; claimed through bit 15 of the first source's 16-bit field
                 const int mi = (f.gx0 - x0 + NEAR_R) * NEAR_W + (f.gy0 - y0 + NEAR_R), sh = (mi & 1) * 16;
                 if (!((atomicOr(&mini[mi >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
-                    const int pos = atomicAdd(&s_nslow, 1);
-                    if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
+                    // every source within the block's walk (steps 0 .. NEAR_R - 1): its events come from that walk;
+                    // otherwise (a source on the block's rim) the scan over all beams
+                    bool inside = true;
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy) {
+                        if (ix >= f.ngx || iy >= f.ngy) continue;
+                        const int ddx = (ix ? f.gx1 : f.gx0) - x0, ddy = (iy ? f.gy1 : f.gy0) - y0;
+                        if (max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy) >= NEAR_R) inside = false;
+                    }
+                    int pos = inside ? atomicAdd(&s_nnear, 1) : NNEAR;
+                    if (pos < NNEAR) {
+                        nearl[pos] = (uint16_t)mykey;
+#pragma unroll
+                        for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                        for (int iy = 0; iy < 2; ++iy) {
+                            if (ix >= f.ngx || iy >= f.ngy) continue;
+                            nid[((ix ? f.gx1 : f.gx0) - x0 + NEAR_R) * NEAR_W + ((iy ? f.gy1 : f.gy0) - y0 + NEAR_R)] = (uint8_t)pos;
+                        }
+                    } else {
+                        pos = atomicAdd(&s_nslow, 1);
+                        if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
+                    }
                 }
                 pflag[mykey] = 0;
             } else {
@@ -579,7 +671,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     const int pos = atomicAdd(&s_nspec, 1);
                     if (pos < RSPEC) spl[pos] = (uint16_t)mykey; else s_fb = 1;
                 }
-                uint16_t* const myev = evl + mykey * ECAP;
+                uint16_t* myev = evl + mykey * ECAP;
                 const int q0 = rpos[b];
                 for (int dir = 0; dir < 2 && act; ++dir) {                          // dir 0: b and the steeper slopes, dir 1: the flatter ones
                     for (int q = dir ? q0 - 1 : q0; dir ? q >= cst : q < cen; q += dir ? -1 : 1) {
@@ -598,9 +690,17 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                             const bool occ_r = (rr.x >> 24) & 1u, nearev = rem == 1 && ((rr.x >> 25) & 1u);
                             const int rank = rem == 0 ? (occ_r ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
                             if ((rank == EV_OCC && (rb << 1) < mykey) || (nearev && (rb << 1 | 1) < mykey)) { act = false; break; }
-                            if (nev < ECAP) myev[nev] = (uint16_t)(rb << 3 | rank);
+                            if (nev + 2 > cap && cap == ECAP && !special) {                // the list is full: move to a long one
+                                slot = atomicAdd(&s_npool, 1);
+                                if (slot < NPOOL) {
+                                    uint16_t* const pl = pool + slot * PCAP;
+                                    for (int i = 0; i < nev; ++i) pl[i] = myev[i];
+                                    myev = pl; cap = PCAP;
+                                } else slot = -1;
+                            }
+                            if (nev < cap) myev[nev] = (uint16_t)(rb << 3 | rank);
                             ++nev;
-                            if (nearev) { if (nev < ECAP) myev[nev] = (uint16_t)(rb << 3 | EV_NEAR); ++nev; }
+                            if (nearev) { if (nev < cap) myev[nev] = (uint16_t)(rb << 3 | EV_NEAR); ++nev; }
                         }
                         if (!act) break;
                     }
@@ -614,11 +714,12 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             oldv8[mykey] = (uint8_t)oldv;
             if (pflag[mykey] == 2) {                                               // the other classes add their events in pass 2
                 atomicAdd(&evn32[mykey >> 1], (uint32_t)nev << ((mykey & 1) * 16));
-            } else if (nev > ECAP) {
+            } else if (nev > cap) {
                 const int pos = atomicAdd(&s_nslow, 1);
                 if (pos < RSLOW) slowl[pos] = (uint16_t)mykey; else s_fb = 1;
-            } else fin = true;
+            } else if (slot < 0) fin = true;
         }
+        if (slot >= 0 && slot < NPOOL) poolkey[slot] = act && nev <= cap ? (uint32_t)mykey | ((uint32_t)nev << 16) : 0xFFFFFFFFu;
         const int nmax = wave_max(fin ? nev : 0);
         if (fin) {
             const uint16_t* myev = evl + mykey * ECAP;
@@ -629,6 +730,33 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     BAR_LDS();
     STAMP(3);
+    {   // long lists (17 .. PCAP events): a wave sorts by counting and folds the clamped adds with a shuffle tree
+        const int npool = UNI(min(s_npool, NPOOL));
+        for (int k = wave; k < npool; k += RB / 64) {
+            const uint32_t pk = poolkey[k];
+            if (pk == 0xFFFFFFFFu) continue;
+            const int key = (int)(pk & 0xFFFFu), m = (int)(pk >> 16);
+            const uint32_t ekey = lane < m ? (uint32_t)pool[k * PCAP + lane] : 0xFFFFFFFFu;
+            int rank = 0;
+            for (int e = 0; e < m; ++e) {
+                const uint32_t ke = (uint32_t)__shfl((int)ekey, e, 64);
+                rank += (ke < ekey) || (ke == ekey && e < lane);
+            }
+            const uint32_t sorted = (uint32_t)__builtin_amdgcn_ds_permute((lane < m ? rank : lane) << 2, (int)ekey);
+            const int BIG = 1000000;
+            Caf fc = {0, -BIG, BIG};
+            if (lane < m) {
+                const int rk = (int)(sorted & 7u);
+                fc = rk == EV_OCC ? Caf{v.cc.occ, -BIG, v.cc.vmax} : rk == EV_NEAR ? Caf{v.cc.nearby, -BIG, v.cc.vmax} : Caf{v.cc.emp, v.cc.vmin, BIG};
+            }
+            for (int off = 1; off < 64; off <<= 1) {
+                Caf g;
+                g.a = __shfl_down(fc.a, off, 64); g.lo = __shfl_down(fc.lo, off, 64); g.hi = __shfl_down(fc.hi, off, 64);
+                if ((lane & (2 * off - 1)) == 0) fc = caf_then(fc, g);
+            }
+            if (lane == 0) oval[key] = (uint8_t)(caf_apply(fc, (int)(int8_t)oldv8[key]) - v.cc.vmin);
+        }
+    }
     // ---- pass 2b: cells other classes reach too; one lane per (cell, other class) ----
     {
         const int nspec = UNI(min(s_nspec, RSPEC));
@@ -702,6 +830,114 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     BAR_LDS();
     if (UNI(s_fb)) { GIVE_BACK(UNI(s_nslow) > RSLOW || UNI(s_nspec) > RSPEC ? 3 : 2); }
+    // ---- flagged cells inside the block: their events come from a second walk of the block.  All unoccupied passes
+    //      are the same clamped add, so only their NUMBER between consecutive occupied / nearby events (in beam order)
+    //      matters: a wave per cell sorts those few events and counts the passes into the intervals they bound. ----
+    {
+        const int nnear = UNI(min(s_nnear, NNEAR));
+        if (nnear > 0) {
+            int* const ncur = reinterpret_cast<int*>(cnt);                         // [NNEAR] fill pointers (the event lists of the passes above are done with)
+            int* const nend = ncur + NNEAR;                                        // [NNEAR] end of the cell's list
+            int* const nbeg = nend + NNEAR;                                        // [NNEAR]
+            uint16_t* const wsp = reinterpret_cast<uint16_t*>(nbeg + NNEAR);       // [waves][NSPC] sorted occupied / nearby events
+            int* const wcnt = reinterpret_cast<int*>(wsp + (RB / 64) * NSPC);      // [waves][NSPC + 1] passes per interval
+            uint16_t* const nev = reinterpret_cast<uint16_t*>(wcnt + (RB / 64) * (NSPC + 1));
+            const int nev_cap = min((G.ncell - (int)((unsigned char*)nev - (unsigned char*)cnt)) / 2, 32767);
+            if (wave == 0) {                                                       // list sizes: the passes counted by the first walk + room for nearby events
+                int run = 0;
+                for (int i0 = 0; i0 < nnear; i0 += 64) {
+                    const int id = i0 + lane;
+                    int need = 0;
+                    if (id < nnear) {
+                        FCell f;
+                        cell_sources(scell[nearl[id]], f);
+#pragma unroll
+                        for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                        for (int iy = 0; iy < 2; ++iy) {
+                            if (ix >= f.ngx || iy >= f.ngy) continue;
+                            const int mi = ((ix ? f.gx1 : f.gx0) - x0 + NEAR_R) * NEAR_W + ((iy ? f.gy1 : f.gy0) - y0 + NEAR_R);
+                            need += (int)((mini[mi >> 1] >> ((mi & 1) * 16)) & 0x7FFFu);
+                        }
+                        need += NSPC;
+                    }
+                    const int ex = run + wave_excl_scan(need, lane);
+                    if (id < nnear) {
+                        const int beg = min(ex, nev_cap), end = min(ex + need, nev_cap);   // a list that does not fit: the scan over all beams
+                        nbeg[id] = beg; ncur[id] = beg; nend[id] = end < ex + need ? beg : end;
+                    }
+                    run += wave_sum(need);
+                }
+            }
+            BAR_LDS();
+            walk_block(true, ncur, nend, nev);
+            BAR_LDS();
+            for (int id = wave; id < nnear; id += RB / 64) {
+                const int key = nearl[id];
+                const int beg = nbeg[id], m = ncur[id] - beg;
+                uint16_t* const sp = wsp + wave * NSPC;
+                int* const ic = wcnt + wave * (NSPC + 1);
+                FCell f;
+                cell_sources(scell[key], f);
+                const int val0 = lane == 0 ? old_value(f) : 0;
+                bool ok = beg + m <= nend[id] && nend[id] > beg;
+                // the occupied / nearby events, sorted by (beam, rank)
+                int k = 0;
+                for (int i0 = 0; i0 < m && ok; i0 += 64) {
+                    const int i = i0 + lane;
+                    const uint32_t ev = i < m ? nev[beg + i] : 0u;
+                    const bool spc = i < m && (ev & 7u) >= (uint32_t)EV_OCC;
+                    const unsigned long long mk = __ballot(spc);
+                    const int at = k + __popcll(mk & ((1ull << lane) - 1ull));
+                    if (spc && at < NSPC) sp[at] = (uint16_t)ev;
+                    k += __popcll(mk);
+                }
+                if (k > NSPC) ok = false;
+                if (!ok) {                                                         // (uniform) too many events: the scan over all beams
+                    if (lane == 0) { const int pos = atomicAdd(&s_nslow, 1); if (pos < RSLOW) slowl[pos] = (uint16_t)key; else s_fb = 1; }
+                    continue;
+                }
+                {
+                    const uint32_t mine = lane < k ? (uint32_t)sp[lane] : 0xFFFFFFFFu;
+                    int rk = 0;
+                    for (int e = 0; e < k; ++e) { const uint32_t o = (uint32_t)__shfl((int)mine, e, 64); rk += (o < mine) || (o == mine && e < lane); }
+                    if (lane <= NSPC) ic[lane] = 0;
+                    if (lane < k) sp[rk] = (uint16_t)mine;                         // (every lane has read its own entry)
+                }
+                // passes: interval = number of occupied / nearby events of smaller beams (a beam's own passes come first)
+                for (int i0 = 0; i0 < m; i0 += 64) {
+                    const int i = i0 + lane;
+                    const uint32_t ev = i < m ? nev[beg + i] : 0xFFFFu;
+                    if (i < m && (ev & 7u) < (uint32_t)EV_OCC) {
+                        const uint32_t bm = ev >> 3;
+                        int iv = 0;
+                        for (int e = 0; e < k; ++e) iv += ((uint32_t)sp[e] >> 3) < bm;
+                        atomicAdd(&ic[iv], 1);
+                    }
+                }
+                {   // lane e <= k: the passes of interval e, then event e; folded in lane order by a shuffle tree
+                    const int BIG = 1000000;
+                    Caf fc = {0, -BIG, BIG};
+                    if (lane <= k) {
+                        const int n = min(ic[lane], sat);
+                        fc = Caf{n * v.cc.emp, v.cc.vmin, BIG};                   // n clamped adds of emp (gridmap.py:97-101) = one with n * emp
+                        if (lane < k) {
+                            const int rk = (int)(sp[lane] & 7u);
+                            fc = caf_then(fc, rk == EV_OCC ? Caf{v.cc.occ, -BIG, v.cc.vmax} : Caf{v.cc.nearby, -BIG, v.cc.vmax});
+                        }
+                    }
+                    for (int off = 1; off < 64; off <<= 1) {
+                        Caf g;
+                        g.a = __shfl_down(fc.a, off, 64); g.lo = __shfl_down(fc.lo, off, 64); g.hi = __shfl_down(fc.hi, off, 64);
+                        if ((lane & (2 * off - 1)) == 0) fc = caf_then(fc, g);
+                    }
+                    if (lane == 0) oval[key] = (uint8_t)(caf_apply(fc, val0) - v.cc.vmin);
+                }
+            }
+            BAR_LDS();
+            if (UNI(s_fb)) { GIVE_BACK(3); }                                       // (the list of cells for the scan over all beams is full)
+        }
+    }
     {   // cells near the sensor and cells with more than ECAP events: exact membership test over all beams, one cell at a
         // time by the whole workgroup.  A lane folds the events of its beam (the clamped adds compose associatively: Caf),
         // a wave folds its 64 consecutive beams with a shuffle tree, thread 0 folds the waves' results in beam order.
@@ -771,37 +1007,16 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         BAR_LDS();
         STAMP(4);
         // ---- walk: lanes are rays, a work item is one 16-step chunk of 64 rays ----
-        // Level k = steps 16k .. 16k + 15.  The rays that own a whole k-th chunk are perm[0 .. N_k) (rays ordered by falling
+        // Level k >= 1 = steps NEAR_R + 16 (k - 1) .. + 15.  The rays that own a whole k-th chunk are perm[0 .. N_k) (rays ordered by falling
         // chunk count), so every lane of an item runs all 16 steps: no predicates.  Lane l of the w-th wave of a level takes
         // ray l * (waves of the level) + w: the 64 rays of one instruction point in different directions and touch
         // different cells.  Step j of a ray is field base0 + j * cj + minor(j) * cm, minor(j) = (fstep * j + 2^21) >> 22:
-        // five instructions and a fire-and-forget LDS add.  Level 0 goes into the 16-bit block (first window only: it
+        // five instructions and a fire-and-forget LDS add.  The first NEAR_R steps went into the 16-bit block (before the windows: it
         // outlives the windows); the last, partial chunk of every ray is a predicated item of its own.
         {
             const int rx0 = x0 - gx_base, ry0 = y0 - gy_base;
             const int base0 = rx0 * stride + ry0;
             const bool whole = S0 == S_lo && S1 == S_hi;                           // one window holds the fan: no row test
-            if (n_win == 0) {
-                const int nw0 = (v.B + 63) >> 6;
-                for (int q = wave; q < nw0; q += RB / 64) {
-                    const int b = lane * nw0 + q;
-                    if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
-                    const uint32_t fs = r_fstep[b];
-                    const uint32_t cc = r_cc[b];
-                    const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
-                    const int dmaj = (int)r_dmaj[b];
-                    const int mj = cj == 1 || cj == -1 ? cj : (cj > 0 ? NEAR_W : -NEAR_W);   // the same steps in the 16-bit block
-                    const int mm = cm == 1 || cm == -1 ? cm : (cm > 0 ? NEAR_W : -NEAR_W);
-                    uint32_t facc = 1u << (RFIX - 1);
-                    int aj = NEAR_R * NEAR_W + NEAR_R;
-#pragma unroll
-                    for (int u = 0; u < NEAR_R; ++u) {
-                        const int c = aj + __mul24((int)(facc >> RFIX), mm);
-                        atomicAdd(&mini[c >> 1], u <= dmaj ? 1u << ((c & 1) * 16) : 0u);      // (a step past the end stays inside the block: adds nothing)
-                        facc += fs; aj += mj;
-                    }
-                }
-            }
             const int nlev = UNI(s_nlev);                                          // levels 1 .. nlev have whole chunks
             const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
             for (int q = wave; q < nitems; q += RB / 64) {
@@ -814,12 +1029,12 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const uint32_t fs = r_fstep[b];
                 const uint32_t cc = r_cc[b];
                 const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
-                const int j0 = k * NEAR_R;
+                const int j0 = NEAR_R + (k - 1) * LCH;
                 uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
                 int aj = base0 + __mul24(j0, cj);
                 if (whole) {
 #pragma unroll
-                    for (int u = 0; u < NEAR_R; ++u) {
+                    for (int u = 0; u < LCH; ++u) {
                         const int c = aj + __mul24((int)(facc >> RFIX), cm);
                         atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
                         facc += fs; aj += cj;
@@ -829,7 +1044,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
                     int rowj = rx0 + j0 * rj;
 #pragma unroll
-                    for (int u = 0; u < NEAR_R; ++u) {
+                    for (int u = 0; u < LCH; ++u) {
                         const int m = (int)(facc >> RFIX);
                         const bool in = (unsigned)(rowj + m * rm) < (unsigned)rows_w;
                         const int c = in ? aj + __mul24(m, cm) : 4 * lane;                 // outside the strip: nothing added, a word of the lane's own
@@ -842,7 +1057,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             for (int b = tid; b < v.B; b += RB) {
                 const int dmaj = (int)r_dmaj[b];
                 if (!(r_info[b] & RI_VALID) || dmaj < NEAR_R) continue;
-                const int j0 = ((dmaj + 1) / NEAR_R) * NEAR_R;                     // first step after the whole chunks
+                const int j0 = NEAR_R + ((dmaj + 1 - NEAR_R) / LCH) * LCH;         // first step after the whole chunks
                 if (j0 > dmaj) continue;
                 const uint32_t fs = r_fstep[b];
                 const uint32_t cc = r_cc[b];
@@ -854,7 +1069,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const int left = dmaj - j0;
                 if (whole) {
 #pragma unroll
-                    for (int u = 0; u < NEAR_R - 1; ++u) {                         // branch-free: a dead step adds nothing to a word of the lane's own
+                    for (int u = 0; u < LCH - 1; ++u) {                            // branch-free: a dead step adds nothing to a word of the lane's own
                         const bool in = u <= left;
                         const int c = in ? aj + __mul24((int)(facc >> RFIX), cm) : 4 * lane;
                         atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
@@ -862,7 +1077,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < NEAR_R - 1; ++u) {
+                    for (int u = 0; u < LCH - 1; ++u) {
                         const int m = (int)(facc >> RFIX);
                         const bool in = u <= left && (unsigned)(rowj + m * rm) < (unsigned)rows_w;
                         const int c = in ? aj + __mul24(m, cm) : 4 * lane;

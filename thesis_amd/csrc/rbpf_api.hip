@@ -246,9 +246,10 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_early, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming | hipEventDisableSystemFence));
         {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle, =fan / =ray run only that kernel
+            // (and windows behind it), =chain runs all three in a row
             // before it (tests, comparisons); default: whole-fan kernel, global-index kernel for the fans it cannot hold
             const char* mk = getenv("RBPF_MAP_KERNEL");
-            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : (mk && std::string(mk) == "fan") ? 2 : (mk && std::string(mk) == "ray") ? 3 : 0;
+            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : (mk && std::string(mk) == "fan") ? 2 : (mk && std::string(mk) == "ray") ? 3 : (mk && std::string(mk) == "chain") ? 4 : 0;
             const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
             v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
             v.ndt_refine = h->cfg.ndt_refine;

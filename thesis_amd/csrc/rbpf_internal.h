@@ -54,8 +54,8 @@ struct DevView {
     int32_t* mu_fallback;              // [P] != 0: the map-update kernel that ran first gave the particle back to the next one
     int32_t* mu_hint;                  // [3][2] (attempts, geometry give-backs) of the whole-fan kernel's last launches, rotating by step
     int mu_step;                       // launch counter of the map update (selects the mu_hint slot)
-    int mu_mode;                       // 0 = whole-fan kernel, then the global-index kernel for what it gave back, then 128x128 windows;
-                                       // 1 = 128x128 windows only; 2 = whole-fan kernel, then windows; 3 = global-index kernel, then windows
+    int mu_mode;                       // 0 = global-index kernel, then 128x128 windows for what it gave back; 1 = 128x128 windows only;
+                                       // 2 = whole-fan kernel, then windows; 3 = as 0, explicitly; 4 = whole-fan, global-index, windows
     uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
     int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
     int32_t* dup_of; int dups_valid;    // representative of each particle's group of exact duplicates since the last resample (kernels_resample.hip); valid until the next proposal
