@@ -115,6 +115,18 @@ __device__ __forceinline__ uint32_t ray_fix_slope(int dmin, int dmaj) {
     return dmaj ? (((uint32_t)dmin << RFIX) + (uint32_t)dmaj - 1u) / (uint32_t)dmaj : 0u;
 }
 
+// Fire-and-forget adds on hit fields, addressed by field index + the array's LDS address folded into the index (the
+// addresses are multiples of 4, so the field's position inside its word is unchanged): the LDS instruction takes the
+// masked index as its address, without a separate add of the array's base.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ int lds_addr(const void* p) { return (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p; }
+__device__ __forceinline__ void fld8_add(int cabs, uint32_t one) {      // 8-bit fields; cabs = index + lds_addr(array); one = 1 or 0
+    __hip_atomic_fetch_add((lds_u32*)(uintptr_t)(uint32_t)(cabs & ~3), one << ((cabs & 3) * 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void fld16_add(int cabs, uint32_t one) {     // 16-bit fields; cabs = index + lds_addr(array) / 2
+    __hip_atomic_fetch_add((lds_u32*)(uintptr_t)(uint32_t)((cabs << 1) & ~3), one << ((cabs & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // byte-wise min(field, sat) of four unflagged 7-bit hit counts; flagged bytes (bit 7: the field holds a replayed value)
 // pass through
 __device__ __forceinline__ uint32_t premin4(uint32_t x, uint32_t satb, uint32_t sadd) {
@@ -164,6 +176,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     __shared__ int s_nslow, s_written, s_nspec, s_nact, s_exact, s_nnear, s_npool;
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
+    __shared__ double s_sincos[2];
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LL = v.L * v.L;
@@ -179,8 +192,11 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     const double pre_x1 = pb1 < v.B ? v.bx[pb1] : 0.0, pre_y1 = pb1 < v.B ? v.by[pb1] : 0.0;
     const int pre_f0 = pb0 < v.B ? v.bflags[pb0] : 0, pre_f1 = pb1 < v.B ? v.bflags[pb1] : 0;
     const double s_px = v.upd_pose[p], s_py = v.upd_pose[v.P + p];
-    double s_s, s_c;
-    sincos(v.upd_pose[2 * v.P + p], &s_s, &s_c);
+    if (wave == 0) {   // one wave takes the sine and cosine (a few hundred instructions); the others read them after the first barrier
+        double sn, cs_;
+        sincos(v.upd_pose[2 * v.P + p], &sn, &cs_);
+        if (lane == 0) { s_sincos[0] = sn; s_sincos[1] = cs_; }
+    }
     const int x0 = UNI(trunc_to_int(s_px / v.cs)), y0 = UNI(trunc_to_int(s_py / v.cs));   // hybridmap.py:102
     {
         int lx, ly;                                                          // hybridmap.py:98-100
@@ -213,6 +229,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     for (int i = tid; i < (2 * G.bpad + 3) / 4; i += RB) reinterpret_cast<uint32_t*>(oval)[i] = 0xFFFFFFFFu;
     __syncthreads();
     STAMP(0);
+    const double s_s = s_sincos[0], s_c = s_sincos[1];
 
     const int C = v.R * v.dim + v.dim / 2;
     const int Uxs = UNI(ux[x0 - fxl]), Uys = UNI(uy[y0 - fyl]);
@@ -479,10 +496,10 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             uint32_t facc = 1u << (RFIX - 1);
             int aj = NEAR_R * NEAR_W + NEAR_R;
             if (!collect) {
+                aj += lds_addr(mini) >> 1;
 #pragma unroll
                 for (int u = 0; u < NEAR_R; ++u) {
-                    const int c = aj + __mul24((int)(facc >> RFIX), mm);
-                    atomicAdd(&mini[c >> 1], u <= dmaj ? 1u << ((c & 1) * 16) : 0u);      // (a step past the end stays inside the block: adds nothing)
+                    fld16_add(aj + __mul24((int)(facc >> RFIX), mm), u <= dmaj ? 1u : 0u);   // (a step past the end stays inside the block: adds nothing)
                     facc += fs; aj += mj;
                 }
             } else {
@@ -1017,6 +1034,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const int rx0 = x0 - gx_base, ry0 = y0 - gy_base;
             const int base0 = rx0 * stride + ry0;
             const bool whole = S0 == S_lo && S1 == S_hi;                           // one window holds the fan: no row test
+            const int cnt_lds = lds_addr(cnt);
             const int nlev = UNI(s_nlev);                                          // levels 1 .. nlev have whole chunks
             const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
             for (int q = wave; q < nitems; q += RB / 64) {
@@ -1033,10 +1051,10 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
                 int aj = base0 + __mul24(j0, cj);
                 if (whole) {
+                    aj += cnt_lds;
 #pragma unroll
                     for (int u = 0; u < LCH; ++u) {
-                        const int c = aj + __mul24((int)(facc >> RFIX), cm);
-                        atomicAdd(&cnt[c >> 2], 1u << ((c & 3) * 8));
+                        fld8_add(aj + __mul24((int)(facc >> RFIX), cm), 1u);
                         facc += fs; aj += cj;
                     }
                 } else {
@@ -1068,11 +1086,11 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 int rowj = rx0 + j0 * rj;
                 const int left = dmaj - j0;
                 if (whole) {
+                    aj += cnt_lds;
 #pragma unroll
                     for (int u = 0; u < LCH - 1; ++u) {                            // branch-free: a dead step adds nothing to a word of the lane's own
                         const bool in = u <= left;
-                        const int c = in ? aj + __mul24((int)(facc >> RFIX), cm) : 4 * lane;
-                        atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
+                        fld8_add(in ? aj + __mul24((int)(facc >> RFIX), cm) : cnt_lds + 4 * lane, in ? 1u : 0u);
                         facc += fs; aj += cj;
                     }
                 } else {
