@@ -89,6 +89,7 @@ static const int WCH = 32;              // samples weighted per pass over the be
 __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
     __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
     __shared__ int s_sum[KMAX];
+    __shared__ float4 s_q[KMAX];                       // single-precision sample frame in home-tile cells: (cos, sin) / cell, offset x, y
     __shared__ int s_tab[49];
     __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
     __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
         if (tid == 0) { v.upd_pose[p] = v.px[p]; v.upd_pose[v.P + p] = v.py[p]; v.upd_pose[2 * v.P + p] = v.pth[p]; }
         return;
     }
+    const HomeTile home = home_tile(v, s_tab, s_mean[0], s_mean[1]);
+    const double inv_cs = (double)v.dim / v.tile_len;
     if (tid < K) {
         double g[3];
         if (a.guesses) {
@@ -149,18 +152,24 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
         double sn, cs;
         sincos(g[2], &sn, &cs);
         s_c[tid] = cs; s_s[tid] = sn; s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
+        s_q[tid] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(g[0] * inv_cs + (double)home.off_x), (float)(g[1] * inv_cs + (double)home.off_y));
         s_sum[tid] = 0;
     }
     __syncthreads();
 
     // ---- weighting: K gathers per beam.  The samples of a beam end on neighbouring cells (one or two cache lines), so
-    //      a beam's K look-ups are done together.  Eight at a time: eight cell addresses in the particle's home tile are
+    //      a beam's K look-ups are done together, eight at a time: eight cell addresses in the particle's home tile are
     //      formed without a branch, the eight byte loads are issued back to back, then added - nothing waits on a single
-    //      load.  A look-up that is not safely inside a cell of the home tile (lookup_cell_home) is rare and goes the
-    //      general, exact way afterwards. -------------------------------------------------------------------------
-    const HomeTile home = home_tile(v, s_tab, s_mean[0], s_mean[1]);
+    //      load.  The address comes from SINGLE-precision arithmetic in home-tile cell coordinates.  Error budget, in
+    //      cells, for |rotated beam| <= 1.5 dim and |result| < dim: the conversions of x, y, cos / cell, sin / cell cost
+    //      4 * 1.5 dim * 2^-24, the offset's rounding dim * 2^-24, the two fused multiply-adds 2.5 dim * 2^-24 and
+    //      dim * 2^-24: 9.5 dim * 2^-24 = 4.5e-4 at dim = 800, 1.2e-3 at 2048.  The address is taken only when the point
+    //      lies more than WSAFE (1e-3 for dim <= 1024, else 2e-3) inside its cell on both axes: the cell index is then the
+    //      reference's (gridmap.py:119-128 on the float64 point).  The other 0.4 - 0.8 % of the look-ups are redone in
+    //      float64 the reference's way (lookup_cell_home) once the beam's fast ones are out. -------------------------
     const int8_t* const hbase = home.ok ? home.base : v.pool;
-    const double inv_cs = (double)v.dim / v.tile_len, half_safe = 0.5 - 1e-6;
+    const float WSAFE = v.dim <= 1024 ? 1e-3f : 2e-3f;
+    const bool f32_ok = home.ok && v.dim <= 2048;
     for (int k0 = 0; k0 < K; k0 += WCH) {
         int acc[WCH];
 #pragma unroll
@@ -168,40 +177,41 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
         for (int b = tid; b < v.B; b += BLOCK) {
             if (!(v.bflags[b] & BF_WEIGHT)) continue;                 // robot.py:130
             const double x = v.bx[b], y = v.by[b];
+            const float x32 = (float)x, y32 = (float)y;
+            const bool beam_ok = f32_ok && (fabsf(x32) + fabsf(y32)) * (float)inv_cs <= 1.5f * (float)v.dim;   // the error budget's premise
+            uint32_t redo = 0;
 #pragma unroll
             for (int kb = 0; kb < WCH; kb += 8) {
                 if (k0 + kb >= K) break;                              // uniform
                 int addr[8]; bool fast[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int k = min(k0 + kb + u, K - 1);
-                    const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];   // lidar.py:123
-                    const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
-                    const double cx = gx * inv_cs, cy = gy * inv_cs;              // in cells
-                    const double fx = __builtin_floor(cx), fy = __builtin_floor(cy);
-                    const int ix = (int)fx + home.off_x, iy = (int)fy + home.off_y;
-                    // safely inside a cell on both axes: one minimum, one comparison (each comparison costs scalar mask work)
-                    const double margin = fmin(half_safe - fabs((cx - fx) - 0.5), half_safe - fabs((cy - fy) - 0.5));
-                    fast[u] = home.ok && k0 + kb + u < K && margin > 0.0 && max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim;
+                    const bool live = k0 + kb + u < K;
+                    const float4 q = s_q[min(k0 + kb + u, K - 1)];
+                    const float cx = fmaf(q.x, x32, fmaf(-q.y, y32, q.z)), cy = fmaf(q.y, x32, fmaf(q.x, y32, q.w));   // lidar.py:123, in cells
+                    const float fx = floorf(cx), fy = floorf(cy);
+                    const int ix = (int)fx, iy = (int)fy;
+                    const float rx = cx - fx, ry = cy - fy;
+                    fast[u] = beam_ok && live && fminf(rx, ry) > WSAFE && fmaxf(rx, ry) < 1.0f - WSAFE && max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim;
                     addr[u] = fast[u] ? (int)__umul24(ix, v.dim) + iy : 0;
+                    if (live && !fast[u]) redo |= 1u << (kb + u);
                 }
                 int val[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) val[u] = hbase[addr[u]];
                 // (the empty statement keeps the eight loads together: the compiler would otherwise sink each into the
-                // branch that uses it and wait for it there, one load at a time)
+                // select that uses it and wait for it there, one load at a time)
                 asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    acc[kb + u] += fast[u] ? val[u] : 0;
-                    if (!fast[u] && k0 + kb + u < K) {
-                        const int k = k0 + kb + u;
-                        const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];
-                        const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
-                        int vv;
-                        if (lookup_cell_fast_b(v, s_tab, s_base, gx, gy, vv)) acc[kb + u] += vv;
-                    }
-                }
+                for (int u = 0; u < 8; ++u) acc[kb + u] += fast[u] ? val[u] : 0;
+            }
+            while (redo) {                                            // float64, the reference's operations
+                const int k = k0 + __ffs(redo) - 1;
+                redo &= redo - 1;
+                const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];   // lidar.py:123
+                const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
+                int vv;
+                if (lookup_cell_home(v, home, s_tab, s_base, gx, gy, vv)) atomicAdd(&s_sum[k], vv);
             }
         }
 #pragma unroll
