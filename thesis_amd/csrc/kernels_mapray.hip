@@ -177,6 +177,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
     __shared__ double s_sincos[2];
+    __shared__ uint8_t s_ggf[96];                     // 32-column storage group g (from T_lo >> 5): a glitched column among its 33
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LL = v.L * v.L;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     for (int i = tid; i < LL; i += RB) { s_need[i] = 0; s_tab[i] = tab[i]; }
     bins32[tid] = 0;
+    if (tid < 96) s_ggf[tid] = 0;
     if (tid <= MAXLEV) s_lcnt[tid] = 0;
     for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += RB) mini[i] = 0;
     for (int i = tid; i < (NEAR_W * NEAR_W + 3) / 4; i += RB) reinterpret_cast<uint32_t*>(nid)[i] = 0xFFFFFFFFu;
@@ -366,7 +368,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
     for (int lc = tid; lc < stride + 16 && lc < G.fanw + 16; lc += RB) {       // column glitch mask in window coordinates
         const int i = lc + gy_base - fyl;
-        gym[lc] = (i >= 0 && i < nfx && gyb[i]) ? 0xFFu : 0u;
+        const bool gl = i >= 0 && i < nfx && gyb[i];
+        gym[lc] = gl ? 0xFFu : 0u;
+        if (gl) {   // the write-back's 32-column groups that see this column: its own and, for a group's first four columns, the one before
+            const int sc = lc + gy_base + C, g = (sc >> 5) - (T_lo >> 5);
+            if ((unsigned)g < 96u) s_ggf[g] = 1;
+            if ((sc & 31) < 4 && (unsigned)(g - 1) < 96u) s_ggf[g - 1] = 1;
+        }
     }
     uint32_t* const farh = cnt;                                                // [8 * NBIN] 16-bit counts of the rays longer than the 16-bit block (the window is not in use yet)
     farh[tid] = 0;
@@ -1160,17 +1168,23 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     const int lc0 = 32 * Gy - C - gy_base;                             // window column of the group's first cell, multiple of 4
                     uint32_t n[8];
                     uint32_t any = 0;
-                    {
-                        // glitched columns in the group (its 32 cells and the one after)?
+                    const bool both = va && vb;
+                    if (!both && !s_ggf[Gy - (T_lo >> 5)]) {   // one source row, no glitched column: the fields are the group's counts
+                        const int rowo = (lr + (va ? 0 : 1)) * stride + lc0;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            const int lc = lc0 + 4 * w;
+                            n[w] = (lc >= 0 && lc < stride) ? cnt[(rowo + 4 * w) >> 2] : 0u;
+                            any |= n[w];
+                        }
+                    } else {
+                        // glitched columns in the group (its 32 cells and the one after)
                         uint32_t gm[9];
-                        uint32_t gany = 0;
 #pragma unroll
                         for (int w = 0; w < 9; ++w) {
                             const int lc = lc0 + 4 * w;
                             gm[w] = (lc >= 0 && lc < stride + 12) ? *reinterpret_cast<const uint32_t*>(gym + lc) : 0u;
-                            gany |= gm[w];
                         }
-                        const bool both = va && vb;
 #pragma unroll
                         for (int w = 0; w < 8; ++w) n[w] = 0;
                         for (int src = 0; src < 2; ++src) {
@@ -1182,18 +1196,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                                 const int lc = lc0 + 4 * w;
                                 x[w] = (lc >= 0 && lc < stride) ? cnt[(row * stride + lc) >> 2] : 0u;
                             }
-                            if (!gany && !both) {
 #pragma unroll
-                                for (int w = 0; w < 8; ++w) n[w] = x[w];
-                            } else {
+                            for (int w = 0; w < 9; ++w) x[w] = premin4(x[w], satb, sadd);
 #pragma unroll
-                                for (int w = 0; w < 9; ++w) x[w] = premin4(x[w], satb, sadd);
-#pragma unroll
-                                for (int w = 0; w < 8; ++w) {
-                                    const uint32_t keep = x[w] & ~gm[w];
-                                    const uint32_t mv = ((x[w] & gm[w]) >> 8) | ((x[w + 1] & gm[w + 1]) << 24);
-                                    n[w] += keep + mv;
-                                }
+                            for (int w = 0; w < 8; ++w) {
+                                const uint32_t keep = x[w] & ~gm[w];
+                                const uint32_t mv = ((x[w] & gm[w]) >> 8) | ((x[w + 1] & gm[w + 1]) << 24);
+                                n[w] += keep + mv;
                             }
                         }
 #pragma unroll
