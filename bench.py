@@ -110,7 +110,7 @@ class Runner:
         self.frame += 1
 
 
-KERNEL_NAMES = {"raycast": "rbpf::map_update_fan_kernel",        # (the family's other kernels - global-index, windows - exit at once when it gave nothing back) "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
+KERNEL_NAMES = {"raycast": "rbpf::map_update_ray_kernel",        # (the family's other kernel - 128x128 windows - exits at once when the first gave nothing back) "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
                 "weight": "rbpf::propose_weight_kernel", "resample": "rbpf::resample_copy_kernel"}
 
 
