@@ -98,7 +98,7 @@ typedef struct rbpf_counters {
     double   ms_resample;         /* ... of the last resample (plan + copies)                     */
     uint64_t slow_cells;          /* flagged cells replayed by the exact membership scan          */
     uint64_t reserved[7];         /* phase cycle sums of a -DRBPF_STAMPS diagnostic build, else 0 */
-    uint64_t window_fallbacks;    /* particles the whole-fan map update handed to the 128x128-window kernel */
+    uint64_t window_fallbacks;    /* particles the first map-update kernel handed to the 128x128-window kernel */
     uint64_t ndt_runs;            /* matches that entered the NDT stage                           */
     uint64_t ndt_evaluations;     /* NDT score/gradient/Hessian evaluations, summed over runs     */
     uint64_t ndt_accepted;        /* runs whose pose replaced the grid pose (matchScanCustom.m:39-41) */

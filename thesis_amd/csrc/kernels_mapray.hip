@@ -9,16 +9,17 @@
 //     SURVEY quirk 3) mis-rounds.  The index map is verified per particle to have the form U(g) = g + C - G(g),
 //     G(g) in {0,1} (it can only round DOWN); the write-back folds it in: storage cell s receives global cell s - C
 //     when that one is not glitched, plus global cell s - C + 1 when that one is.
-//   * Lanes run ALONG a ray: a wave takes one ray and its 64 lanes take 64 consecutive steps, each from the closed
-//     form minor(j) = (fstep * j + 2^21) >> 22 (rbpf_math.h / fix_slope).  Per-ray quantities are wave-uniform (scalar
-//     registers), nothing is carried from step to step, and the adds are fire-and-forget LDS atomics: nothing waits
-//     for a returned value.
+//   * Walk: lanes are rays, a work item is a 16-step chunk of 64 rays, each step from the closed form
+//     minor(j) = (fstep * j + 2^21) >> 22 (rbpf_math.h / fix_slope); the adds are fire-and-forget LDS atomics: nothing
+//     waits for a returned value, nothing is detected.
 //   * Cells that receive an "occupied" / "nearby" hit (the only ones whose clamped adds do not commute) are not found
 //     by the walk.  The rays through a cell at major distance j, minor offset c are exactly those of the matching
 //     direction class whose fixed-point slope lies in [ceil((c*2^22 - 2^21)/j), ceil(((c+1)*2^22 - 2^21)/j)) and that
-//     are longer than j; rays are bucketed by (class, slope >> 14) once per particle, so each such cell GATHERS its
-//     few rays from two or three buckets, sorts the (beam, rank) events in registers and replays them.  This happens
-//     before anything is written, so every table overflow still hands the particle back untouched.
+//     are longer than j; rays are bucketed by (class, slope >> 14) and sorted once per particle, so each such cell
+//     GATHERS its few rays from a contiguous run, sorts the (beam, rank) events in registers and replays them.  Cells
+//     next to the sensor, which most rays cross, take their events from a second walk of the 16-bit block instead and
+//     need only the number of unoccupied passes between consecutive occupied / nearby events.  This happens before
+//     anything is written, so every table overflow still hands the particle back untouched.
 //   * A fan larger than the LDS window is processed in strips of storage rows (one launch, any fan size): cell sizes
 //     of 0.025 m and 15 m rays included.  8-bit counters cannot overflow: a bound on the hits of any cell with j >= 16
 //     is checked from the slope buckets first (cells nearer than NEAR_R steps live in a 16-bit block).
