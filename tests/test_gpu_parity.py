@@ -192,6 +192,26 @@ def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
     e.close()
 
 
+@pytest.mark.parametrize("fixture", ["R1_nearby_cell_diagonal", "R2_nearby_cell_diagonal_tile_edge"])
+def test_map_update_nearby_cell_diagonal_to_the_start_cell(golden, eng_mod, map_kernel, fixture):
+    """Regression (found by tools/fuzz_map_update.py, seed 51): a 0.11 m beam whose cell before the end lies at (-1, -1) from
+    the start cell - the packed relative cell 0xFFFF | 0xFFFF << 16 looked like "no cell" to the global-index kernel and
+    the beam's NEARBY event (hybridmap.py:139-142) was lost.  R2: the same next to a tile edge, second scan of two."""
+    d = golden(fixture)
+    cs, ang = float(d["cs"]), d["ang"]
+    scans = [d["ranges"]] if d["ranges"].ndim == 1 else list(d["ranges"])
+    poses = [d["pose"]] if "pose" in d else list(d["poses"])
+    e = eng_mod.ParticleEngine(1, max_beams=len(ang), cell_size=cs, pool_tiles=40)
+    hm = orc.OracleHybridMap(cs)
+    for r, pose in zip(scans, poses):
+        e.set_scan(r, ang)
+        e.map_update(np.asarray(pose, dtype=np.float64)[None, :])
+        sx, sy = orc.scan_xy(r, ang)
+        hm.update(tuple(float(v) for v in pose), sx, sy)
+    assert_tiles_equal(e, 0, oracle_dump(hm), e.dim)
+    e.close()
+
+
 def test_map_update_ray_cell_count_matches_oracle(eng_mod, map_kernel):
     from thesis_amd.datasets import synthetic
     B = 1081

@@ -57,7 +57,7 @@ static const int HIT_BOUND = 63;               // per direction class; two class
 
 struct RayGeom {
     int fanw, bpad, ncell;
-    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_scell, o_oldv, o_rcc, o_rdmaj, o_perm, o_rpos, o_pflag, o_nid, o_nearl;
+    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_oldv, o_rdmaj, o_perm, o_rpos, o_pflag, o_nid, o_nearl;
     int bytes;
     bool ok;
 };
@@ -82,9 +82,7 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
     g.o_brays = o; o += ray_al16(g.bpad * 2);
     g.o_oval = o;  o += ray_al16(g.bpad * 2);
     g.o_slow = o;  o += RSLOW * 2;
-    g.o_scell = o; o += ray_al16(g.bpad * 8);
     g.o_oldv = o;  o += ray_al16(g.bpad * 2);
-    g.o_rcc = o;   o += ray_al16(g.bpad * 4);
     g.o_rdmaj = o; o += ray_al16(g.bpad * 2);
     g.o_perm = o;  o += ray_al16(g.bpad * 2);
     g.o_rpos = o;  o += ray_al16(g.bpad * 2);
@@ -160,9 +158,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     uint16_t* const brays = reinterpret_cast<uint16_t*>(smem + G.o_brays); // ray ids ordered by (class, slope bucket)
     uint8_t*  const oval = smem + G.o_oval;                                // [2 * B] replayed value - vmin of the cell flagged by (beam, e); 0xFF = none / not the owner
     uint16_t* const slowl = reinterpret_cast<uint16_t*>(smem + G.o_slow);  // [RSLOW] (beam << 1) | e
-    uint32_t* const scell = reinterpret_cast<uint32_t*>(smem + G.o_scell); // [2 * B] storage cell (U_x << 16 | U_y) flagged by (beam, e), ~0 = none
     uint8_t*  const oldv8 = smem + G.o_oldv;                               // [2 * B] its value before the scan
-    uint32_t* const r_cc = reinterpret_cast<uint32_t*>(smem + G.o_rcc);    // [B] window-address steps of the ray: per major step | per minor step << 16
     uint16_t* const r_dmaj = reinterpret_cast<uint16_t*>(smem + G.o_rdmaj); // [B] last step of the ray
     uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole 16-step chunks
     uint16_t* const rpos = reinterpret_cast<uint16_t*>(smem + G.o_rpos);   // [B] position of the ray in brays
@@ -239,6 +235,24 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     const int a0 = Uxs / v.dim, b0 = Uys / v.dim;
     auto lat_x = [&](int g) { const int U = ux[g - fxl]; return a0 + (U >= (a0 + 1) * v.dim ? 1 : 0) - (U < a0 * v.dim ? 1 : 0); };
     auto lat_y = [&](int g) { const int U = uy[g - fyl]; return b0 + (U >= (b0 + 1) * v.dim ? 1 : 0) - (U < b0 * v.dim ? 1 : 0); };
+    // the storage cell (U_x << 16 | U_y) flagged by pair (beam, e): the beam's end cell (e = 0) or the cell before it (e = 1,
+    // only when it lies in the end cell's tile); ~0 = none.  And the ray's window-address steps (per major / minor step).
+    auto pair_cell = [&](int pr) -> uint32_t {
+        const int b = pr >> 1, info = r_info[b];
+        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC) || ((pr & 1) && !(info & RI_NEAR))) return 0xFFFFFFFFu;
+        const int32_t re = r_end[b];
+        int x1 = x0 + (int)(int16_t)(re & 0xFFFF), y1 = y0 + (int)(int16_t)((uint32_t)re >> 16);
+        if (pr & 1) { x1 += ((info >> 3) & 3) - 1; y1 += ((info >> 5) & 3) - 1; }
+        return ((uint32_t)ux[x1 - fxl] << 16) | (uint32_t)uy[y1 - fyl];
+    };
+    auto pair_gcell = [&](int pr) -> uint32_t {          // the same as a global cell relative to the start, biased: never ~0
+        const int b = pr >> 1, info = r_info[b];
+        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC) || ((pr & 1) && !(info & RI_NEAR))) return 0xFFFFFFFFu;
+        const int32_t re = r_end[b];
+        int dx = (int)(int16_t)(re & 0xFFFF), dy = (int)(int16_t)((uint32_t)re >> 16);
+        if (pr & 1) { dx += ((info >> 3) & 3) - 1; dy += ((info >> 5) & 3) - 1; }
+        return (uint32_t)(dx + 0x4000) | ((uint32_t)(dy + 0x4000) << 16);
+    };
     // direction class and slope bucket of a ray
     auto ray_key = [&](int ddx, int ddy, uint32_t fstep) {
         const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
@@ -269,17 +283,15 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             Ray r = ray_make(x0, y0, x1, y1);
             int info = 0;
             uint32_t fstep = 0;
-            uint32_t sc0 = 0xFFFFFFFFu, sc1 = 0xFFFFFFFFu;
             if (r.n > 0) {
                 info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
-                if (info & RI_OCC) sc0 = ((uint32_t)ux[x1 - fxl] << 16) | (uint32_t)uy[y1 - fyl];
                 my_cells += (unsigned long long)r.n;
                 fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
                 const int a1 = lat_x(x1), b1 = lat_y(y1);
                 if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
                     int nx, ny;
                     ray_point(r, r.n - 2, nx, ny);
-                    if (lat_x(nx) == a1 && lat_y(ny) == b1) { info |= RI_NEAR; sc1 = ((uint32_t)ux[nx - fxl] << 16) | (uint32_t)uy[ny - fyl]; }   // hybridmap.py:141 same tile as the end cell
+                    if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;          // hybridmap.py:141 same tile as the end cell
                     info |= ((nx - x1 + 1) & 3) << 3;
                     info |= ((ny - y1 + 1) & 3) << 5;
                 }
@@ -307,7 +319,6 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             r_dmaj[b] = (uint16_t)(r.n > 0 ? r.dmaj : 0);
             r_info[b] = (uint8_t)info;
             r_fstep[b] = fstep;
-            scell[2 * b] = sc0; scell[2 * b + 1] = sc1;
         }
         {
             const int ws = wave_sum((int)my_cells);
@@ -392,6 +403,14 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         bins32[tid] = (uint32_t)excl | ((uint32_t)(excl + c0) << 16);
     }
     BAR_LDS();
+    // window-address steps of a ray: per major step (cj) and per minor step (cm)
+    auto ray_steps = [&](int b, int& cj, int& cm) {
+        const int32_t re = r_end[b];
+        const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
+        const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+        const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
+        cj = aey > aex ? sy1 : sxs; cm = aey > aex ? sxs : sy1;
+    };
     for (int b = tid; b < v.B; b += RB) {
         if (!(r_info[b] & RI_VALID)) continue;
         const int32_t e = r_end[b];
@@ -399,11 +418,6 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         const int sh = (key & 1) * 16;
         const int pos = (int)((atomicAdd(&bins32[key >> 1], 1u << sh) >> sh) & 0xFFFFu);
         brays[pos] = (uint16_t)b;
-        const int ex = (int)(int16_t)(e & 0xFFFF), ey = (int)(int16_t)((uint32_t)e >> 16);
-        const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
-        const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
-        const int cj = aey > aex ? sy1 : sxs, cm = aey > aex ? sxs : sy1;
-        r_cc[b] = ((uint32_t)cj & 0xFFFFu) | ((uint32_t)cm << 16);
         const int nfull = ((int)r_dmaj[b] + 1 - NEAR_R) / LCH;
         if (nfull >= 1) perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
         if ((int)r_dmaj[b] >= NEAR_R) atomicAdd(&farh[key >> 1], 1u << sh);            // only these reach the 8-bit fields
@@ -497,8 +511,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const int b = lane * nw0 + q;                                          // the 64 rays of an instruction point in different directions
             if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
             const uint32_t fs = r_fstep[b];
-            const uint32_t cc = r_cc[b];
-            const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+            int cj, cm;
+            ray_steps(b, cj, cm);
             const int dmaj = (int)r_dmaj[b];
             const int mj = cj == 1 || cj == -1 ? cj : (cj > 0 ? NEAR_W : -NEAR_W);   // the same steps in the 16-bit block
             const int mm = cm == 1 || cm == -1 ? cm : (cm > 0 ? NEAR_W : -NEAR_W);
@@ -598,15 +612,13 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             else if (i - n1 < v.B && ((int)r_dmaj[i - n1] + 1 - NEAR_R) / LCH < 1) b = i - n1;
             bool play[2] = {false, false};
             if (b >= 0 && (r_info[b] & (RI_VALID | RI_OCC)) == (RI_VALID | RI_OCC)) {
-                for (int e = 0; e < 2; ++e) {
-                    const uint32_t sc = scell[2 * b + e];
-                    if (sc == 0xFFFFFFFFu) break;
-                    // a smaller pair on the same storage cell: this one cannot be the owner (the other duplicates show up in the scan)
-                    bool dup = e == 1 && scell[2 * b] == sc;
-                    if (b >= 1) dup = dup || scell[2 * b - 2] == sc || scell[2 * b - 1] == sc;
-                    if (b >= 2) dup = dup || scell[2 * b - 4] == sc;
-                    if (!dup) { play[e] = true; pflag[2 * b + e] = 3; }              // 3 = in play, not classified yet
-                }
+                // a smaller pair of the neighbouring beams on the same global cell: this one cannot be the owner (the other
+                // duplicates show up in the scan)
+                const uint32_t g0 = pair_gcell(2 * b), g1 = pair_gcell(2 * b + 1);
+                const uint32_t p0 = b >= 1 ? pair_gcell(2 * b - 2) : 0xFFFFFFFFu, p1 = b >= 1 ? pair_gcell(2 * b - 1) : 0xFFFFFFFFu,
+                               q0 = b >= 2 ? pair_gcell(2 * b - 4) : 0xFFFFFFFFu;
+                if (g0 != p0 && g0 != p1 && g0 != q0) { play[0] = true; pflag[2 * b] = 3; }            // 3 = in play, not classified yet
+                if (g1 != 0xFFFFFFFFu && g1 != g0 && g1 != p0 && g1 != p1 && g1 != q0) { play[1] = true; pflag[2 * b + 1] = 3; }
             }
             const unsigned long long m0 = __ballot(play[0]), m1 = __ballot(play[1]);
             int base = 0;
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const int cls = steep * 4 + (ex > 0 ? 2 : 0) + (ey > 0 ? 1 : 0);
             const int cst = bkt_start(cls * NBIN), cen = bkt_end(cls * NBIN + NBIN - 1);
             FCell f;
-            cell_sources(scell[mykey], f);
+            cell_sources(pair_cell(mykey), f);
             oldv = old_value(f);                                                   // in flight during the scan
             // sources along the major and the minor axis of the class frame
             const int gmaj0 = steep ? f.gy0 : f.gx0, gmaj1 = steep ? f.gy1 : f.gx1, nmaj = steep ? f.ngy : f.ngx;
@@ -792,7 +804,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             load_ray(b, me);
             if (cls == me.steep * 4 + (me.ex > 0 ? 2 : 0) + (me.ey > 0 ? 1 : 0)) continue;      // done in pass 1
             FCell f;
-            cell_sources(scell[pair], f);
+            cell_sources(pair_cell(pair), f);
             // slope buckets of this class that can hold a ray through one of the sources
             const int steep = cls >> 2, smaj = steep ? ((cls & 1) ? 1 : -1) : ((cls & 2) ? 1 : -1), smin = steep ? ((cls & 2) ? 1 : -1) : ((cls & 1) ? 1 : -1);
             int blo = NBIN, bhi = -1;
@@ -876,7 +888,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     int need = 0;
                     if (id < nnear) {
                         FCell f;
-                        cell_sources(scell[nearl[id]], f);
+                        cell_sources(pair_cell(nearl[id]), f);
 #pragma unroll
                         for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
@@ -904,7 +916,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 uint16_t* const sp = wsp + wave * NSPC;
                 int* const ic = wcnt + wave * (NSPC + 1);
                 FCell f;
-                cell_sources(scell[key], f);
+                cell_sources(pair_cell(key), f);
                 const int val0 = lane == 0 ? old_value(f) : 0;
                 bool ok = beg + m <= nend[id] && nend[id] > beg;
                 // the occupied / nearby events, sorted by (beam, rank)
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         for (int k = 0; k < nslow; ++k) {
             const int key = UNI(slowl[k]);
             FCell f;
-            cell_sources(scell[key], f);
+            cell_sources(pair_cell(key), f);
             const int val0 = tid == 0 ? old_value(f) : 0;
             for (int base = 0; base < v.B; base += RB) {
                 const int b = base + tid;
@@ -1054,8 +1066,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 if (ii >= nk) continue;
                 const int b = perm[ii];
                 const uint32_t fs = r_fstep[b];
-                const uint32_t cc = r_cc[b];
-                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                int cj, cm;
+                ray_steps(b, cj, cm);
                 const int j0 = NEAR_R + (k - 1) * LCH;
                 uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
                 int aj = base0 + __mul24(j0, cj);
@@ -1087,8 +1099,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const int j0 = NEAR_R + ((dmaj + 1 - NEAR_R) / LCH) * LCH;         // first step after the whole chunks
                 if (j0 > dmaj) continue;
                 const uint32_t fs = r_fstep[b];
-                const uint32_t cc = r_cc[b];
-                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                int cj, cm;
+                ray_steps(b, cj, cm);
                 const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
                 uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
                 int aj = base0 + __mul24(j0, cj);
@@ -1129,7 +1141,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const uint32_t ov = oval[pr];
             if (ov == 0xFFu) continue;
             FCell f;
-            cell_sources(scell[pr], f);
+            cell_sources(pair_cell(pr), f);
             if (f.sx < S0 || f.sx > S1) continue;
 #pragma unroll
             for (int ix = 0; ix < 2; ++ix)

@@ -37,6 +37,7 @@ for case in range(N):
     else:
         centre = np.array([rng.choice([-20, 20, 0, 60, -60]), rng.choice([-20, 20, 0])]) + rng.uniform(-0.3, 0.3, 2)
     ok = True
+    hist = []
     for scan in range(int(rng.integers(1, 4))):
         style = rng.random()
         if style < 0.4:
@@ -49,6 +50,7 @@ for case in range(N):
         poses = np.column_stack([centre[0] + rng.normal(0, 0.4, P), centre[1] + rng.normal(0, 0.4, P), rng.uniform(-np.pi, np.pi, P)])
         e.set_scan(r, ang)
         e.map_update(poses)
+        hist.append((r.copy(), poses.copy()))
         sx, sy = orc.scan_xy(r, ang)
         for p in range(P):
             maps[p].update(poses[p], sx, sy)
@@ -75,6 +77,10 @@ for case in range(N):
             if not np.allclose(w[p], wr, rtol=1e-9, atol=1e-9):
                 ok = False; print("case", case, "weights differ", p, np.abs(w[p] - wr).max()); break
     bad += not ok
+    if not ok:   # keep the inputs of a failing case (gpurun_out/ travels back)
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez(f"gpurun_out/fuzz_fail_{SEED}_{case}.npz", cs=cs, B=B, ang=ang, kernel=kernel,
+                 ranges=np.array([h[0] for h in hist]), poses=np.array([h[1] for h in hist]))
     c = e.counters()
     e.close()
     if case % 20 == 0:
