@@ -44,8 +44,12 @@ for case in range(N):
             r = rng.uniform(0.3, 12.0) + rng.normal(0, 0.3, B).cumsum() * 0.05 + rng.normal(0, 0.02, B)
         elif style < 0.7:
             r = rng.uniform(0.0, 30.0, B)                       # incl. rays longer than 15 m and near-zero ranges
-        else:
+        elif style < 0.85:
             r = np.full(B, rng.uniform(0.5, 9.0)) + rng.normal(0, 0.005, B)
+        else:                                                   # a smooth wall with a fifth of the beams ending next to the sensor
+            r = rng.uniform(2.0, 14.0) + rng.normal(0, 0.3, B).cumsum() * 0.05
+            short = rng.random(B) < 0.2
+            r = np.where(short, rng.uniform(0.0, 0.5, B), r)
         r = np.abs(r)
         poses = np.column_stack([centre[0] + rng.normal(0, 0.4, P), centre[1] + rng.normal(0, 0.4, P), rng.uniform(-np.pi, np.pi, P)])
         e.set_scan(r, ang)
