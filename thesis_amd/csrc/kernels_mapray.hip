@@ -57,7 +57,7 @@ static const int HIT_BOUND = 63;               // per direction class; two class
 
 struct RayGeom {
     int fanw, bpad, ncell;
-    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_oldv, o_rdmaj, o_perm, o_rpos, o_pflag, o_nid, o_nearl;
+    int o_cnt, o_mini, o_rend, o_rinfo, o_fstep, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_bins, o_brays, o_oval, o_slow, o_oldv, o_rcc, o_rdmaj, o_perm, o_rpos, o_pflag, o_nid, o_nearl;
     int bytes;
     bool ok;
 };
@@ -83,6 +83,7 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
     g.o_oval = o;  o += ray_al16(g.bpad * 2);
     g.o_slow = o;  o += RSLOW * 2;
     g.o_oldv = o;  o += ray_al16(g.bpad * 2);
+    g.o_rcc = o;   o += ray_al16(g.bpad * 4);
     g.o_rdmaj = o; o += ray_al16(g.bpad * 2);
     g.o_perm = o;  o += ray_al16(g.bpad * 2);
     g.o_rpos = o;  o += ray_al16(g.bpad * 2);
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     uint8_t*  const oval = smem + G.o_oval;                                // [2 * B] replayed value - vmin of the cell flagged by (beam, e); 0xFF = none / not the owner
     uint16_t* const slowl = reinterpret_cast<uint16_t*>(smem + G.o_slow);  // [RSLOW] (beam << 1) | e
     uint8_t*  const oldv8 = smem + G.o_oldv;                               // [2 * B] its value before the scan
+    uint32_t* const r_cc = reinterpret_cast<uint32_t*>(smem + G.o_rcc);    // [B] window-address steps of the ray: per major step | per minor step << 16
     uint16_t* const r_dmaj = reinterpret_cast<uint16_t*>(smem + G.o_rdmaj); // [B] last step of the ray
     uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole 16-step chunks
     uint16_t* const rpos = reinterpret_cast<uint16_t*>(smem + G.o_rpos);   // [B] position of the ray in brays
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         const int sh = (key & 1) * 16;
         const int pos = (int)((atomicAdd(&bins32[key >> 1], 1u << sh) >> sh) & 0xFFFFu);
         brays[pos] = (uint16_t)b;
+        { int cj, cm; ray_steps(b, cj, cm); r_cc[b] = ((uint32_t)cj & 0xFFFFu) | ((uint32_t)cm << 16); }
         const int nfull = ((int)r_dmaj[b] + 1 - NEAR_R) / LCH;
         if (nfull >= 1) perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
         if ((int)r_dmaj[b] >= NEAR_R) atomicAdd(&farh[key >> 1], 1u << sh);            // only these reach the 8-bit fields
@@ -511,8 +514,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const int b = lane * nw0 + q;                                          // the 64 rays of an instruction point in different directions
             if (b >= v.B || !(r_info[b] & RI_VALID)) continue;
             const uint32_t fs = r_fstep[b];
-            int cj, cm;
-            ray_steps(b, cj, cm);
+            const uint32_t cc = r_cc[b];
+            const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
             const int dmaj = (int)r_dmaj[b];
             const int mj = cj == 1 || cj == -1 ? cj : (cj > 0 ? NEAR_W : -NEAR_W);   // the same steps in the 16-bit block
             const int mm = cm == 1 || cm == -1 ? cm : (cm > 0 ? NEAR_W : -NEAR_W);
@@ -1066,8 +1069,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 if (ii >= nk) continue;
                 const int b = perm[ii];
                 const uint32_t fs = r_fstep[b];
-                int cj, cm;
-                ray_steps(b, cj, cm);
+                const uint32_t cc = r_cc[b];
+                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
                 const int j0 = NEAR_R + (k - 1) * LCH;
                 uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
                 int aj = base0 + __mul24(j0, cj);
@@ -1099,8 +1102,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const int j0 = NEAR_R + ((dmaj + 1 - NEAR_R) / LCH) * LCH;         // first step after the whole chunks
                 if (j0 > dmaj) continue;
                 const uint32_t fs = r_fstep[b];
-                int cj, cm;
-                ray_steps(b, cj, cm);
+                const uint32_t cc = r_cc[b];
+                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
                 const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
                 uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
                 int aj = base0 + __mul24(j0, cj);
