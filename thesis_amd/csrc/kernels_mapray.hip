@@ -1232,27 +1232,23 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     uint32_t occ = 0, touched = 0, out[8];
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {
+                        // branch-free (a word without hits passes through unchanged: dec = 0, no flag, nz = 0)
                         const uint32_t Ob = (pre[w] ^ 0x80808080u) - kb1;                   // cells biased to [0, vmax - vmin]
-                        uint32_t R = Ob;
-                        out[w] = pre[w];
-                        if (n[w]) {
-                            const uint32_t nw = n[w], n7 = nw & 0x7F7F7F7Fu;
-                            const uint32_t ge = (n7 + sadd) & 0x80808080u;                  // fields >= sat
-                            const uint32_t gem = ge | (ge - (ge >> 7));
-                            const uint32_t m = (satb & gem) | (n7 & ~gem);                  // min(n, sat)
-                            const uint32_t dec = eabs == 3 ? m + (m << 1) : m * (uint32_t)eabs;
-                            const uint32_t T1 = (Ob | 0x80808080u) - dec;
-                            const uint32_t pos = T1 & 0x80808080u;                          // O - dec >= 0
-                            R = T1 & 0x7F7F7F7Fu & (pos | (pos - (pos >> 7)));
-                            const uint32_t fl = nw & 0x80808080u;
-                            if (fl) {                                                       // replayed cells: the field holds value - vmin
-                                const uint32_t flm = fl | (fl - (fl >> 7));
-                                R = (n7 & flm) | (R & ~flm);
-                            }
-                            out[w] = (R + kb1) ^ 0x80808080u;
-                            const uint32_t nz = ((n7 + 0x7F7F7F7Fu) | nw) & 0x80808080u;    // fields that are not zero
-                            touched |= __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false) << (4 * w);
-                        }
+                        const uint32_t nw = n[w], n7 = nw & 0x7F7F7F7Fu;
+                        const uint32_t ge = (n7 + sadd) & 0x80808080u;                      // fields >= sat
+                        const uint32_t gem = ge | (ge - (ge >> 7));
+                        const uint32_t m = (satb & gem) | (n7 & ~gem);                      // min(n, sat)
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        const uint32_t dec = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, m) * (us2)(unsigned short)eabs);   // byte-wise: sat * |emp| < 128, no carries
+                        const uint32_t T1 = (Ob | 0x80808080u) - dec;
+                        const uint32_t pos = T1 & 0x80808080u;                              // O - dec >= 0
+                        uint32_t R = T1 & 0x7F7F7F7Fu & (pos | (pos - (pos >> 7)));
+                        const uint32_t fl = nw & 0x80808080u;                               // replayed cells: the field holds value - vmin
+                        const uint32_t flm = fl | (fl - (fl >> 7));
+                        R = (n7 & flm) | (R & ~flm);
+                        out[w] = (R + kb1) ^ 0x80808080u;
+                        const uint32_t nz = ((n7 + 0x7F7F7F7Fu) | nw) & 0x80808080u;        // fields that are not zero
+                        touched |= __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false) << (4 * w);
                         occ |= __builtin_amdgcn_udot4(((R + oadd) & 0x80808080u) >> 7, 0x08040201u, 0u, false) << (4 * w);   // cell > thr
                     }
                     reinterpret_cast<uint4*>(g_ptr)[0] = make_uint4(out[0], out[1], out[2], out[3]);
