@@ -1061,6 +1061,93 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const int cnt_lds = lds_addr(cnt);
             const int nlev = UNI(s_nlev);                                          // levels 1 .. nlev have whole chunks
             const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
+            // one whole chunk of a ray in a strip: every step tests its row
+            auto strip_chunk = [&](int b, int k) {
+                const uint32_t fs = r_fstep[b];
+                const uint32_t cc = r_cc[b];
+                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                const int j0 = NEAR_R + (k - 1) * LCH;
+                uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
+                int aj = base0 + __mul24(j0, cj);
+                // rows: row = rx0 + j * rj + m * rm, where (rj, rm) = (+-1, 0) for a ray along x and (0, +-1) along y
+                const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
+                int rowj = rx0 + j0 * rj;
+#pragma unroll
+                for (int u = 0; u < LCH; ++u) {
+                    const int m = (int)(facc >> RFIX);
+                    const bool in = (unsigned)(rowj + m * rm) < (unsigned)rows_w;
+                    const int c = in ? aj + __mul24(m, cm) : 4 * lane;                     // outside the strip: nothing added, a word of the lane's own
+                    atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
+                    facc += fs; aj += cj; rowj += rj;
+                }
+            };
+            bool by_level = true;
+            int nch_all = 0;                                                       // whole chunks of all rays (uniform)
+            for (int kk = 1; kk <= nlev; ++kk) nch_all += UNI(s_nk[kk]);
+            if (!whole && nch_all <= 65535) {                                      // (16-bit prefixes; decided per particle: the strips share perm's place)
+                // A strip holds a part of every ray: the chunks of a ray that can reach the strip's rows are a run of levels
+                // (exactly for a ray along x, from a single-precision bound with two steps of slack for a ray along y).  Their
+                // counts are prefix-summed over the rays and a lane takes one (ray, chunk) item found by bisection, so that a
+                // strip costs its own share of the walk and not the whole walk again.
+                uint16_t* const cpre = perm;                                       // [B] first item of the ray (the level order is not needed in strips)
+                uint8_t* const cka = pflag;                                        // [B] first level of the ray in this strip
+                int nloc[4], tot = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = 4 * tid + i;
+                    int n = 0;
+                    if (b < v.B && (r_info[b] & RI_VALID)) {
+                        const int nfull = ((int)r_dmaj[b] + 1 - NEAR_R) / LCH;
+                        if (nfull >= 1) {
+                            const uint32_t fs = r_fstep[b];
+                            const uint32_t cc = r_cc[b];
+                            const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                            const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
+                            int jlo = NEAR_R, jhi = NEAR_R + nfull * LCH - 1;
+                            if (rj > 0) { jlo = max(jlo, -rx0); jhi = min(jhi, rows_w - 1 - rx0); }
+                            else if (rj < 0) { jlo = max(jlo, rx0 - rows_w + 1); jhi = min(jhi, rx0); }
+                            else {
+                                const int mlo = max(rm > 0 ? -rx0 : rx0 - rows_w + 1, 0), mhi = rm > 0 ? rows_w - 1 - rx0 : rx0;
+                                if (mhi < mlo) jhi = -1;
+                                else if (fs == 0) { if (mlo > 0) jhi = -1; }                  // the minor offset stays 0
+                                else {   // minor(j) = floor(j * fs / 2^22 + 1/2) in [mlo, mhi]
+                                    const float inv = 4194304.0f / (float)fs;
+                                    jlo = max(jlo, (int)(((float)mlo - 0.5f) * inv) - 2);
+                                    const float ju = ((float)mhi + 0.5f) * inv;
+                                    if (ju < 1.0e9f) jhi = min(jhi, (int)ju + 2);
+                                }
+                            }
+                            if (jhi >= jlo) {
+                                const int ka = 1 + (jlo - NEAR_R) / LCH, kb = 1 + (jhi - NEAR_R) / LCH;
+                                n = kb - ka + 1;
+                                cka[b] = (uint8_t)ka;
+                            }
+                        }
+                    }
+                    nloc[i] = n; tot += n;
+                }
+                int incl = tot;
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                if (lane == 63) s_wsum[wave] = incl;
+                BAR_LDS();
+                int run = incl - tot;
+                for (int k = 0; k < wave; ++k) run += s_wsum[k];
+                int total = 0;
+                for (int k = 0; k < RB / 64; ++k) total += s_wsum[k];
+                total = UNI(total);
+                by_level = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int b = 4 * tid + i; if (b < v.B) cpre[b] = (uint16_t)run; run += nloc[i]; }
+                BAR_LDS();
+                for (int q = wave * 64; q < total; q += RB) {
+                    const int it = q + lane;
+                    if (it >= total) continue;
+                    int b = 0;
+                    for (int st = 2048; st; st >>= 1) { const int cand = b + st; if (cand < v.B && (int)cpre[cand] <= it) b = cand; }
+                    strip_chunk(b, (int)cka[b] + (it - (int)cpre[b]));
+                }
+            }
+            if (by_level)
             for (int q = wave; q < nitems; q += RB / 64) {
                 int k = 1;
                 for (int kk = 2; kk <= nlev; ++kk) if (q >= UNI(s_lp[kk])) k = kk;
@@ -1068,32 +1155,19 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const int ii = lane * nwk + wslot;
                 if (ii >= nk) continue;
                 const int b = perm[ii];
-                const uint32_t fs = r_fstep[b];
-                const uint32_t cc = r_cc[b];
-                const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
-                const int j0 = NEAR_R + (k - 1) * LCH;
-                uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
-                int aj = base0 + __mul24(j0, cj);
                 if (whole) {
-                    aj += cnt_lds;
+                    const uint32_t fs = r_fstep[b];
+                    const uint32_t cc = r_cc[b];
+                    const int cj = (int)(int16_t)(cc & 0xFFFFu), cm = (int)cc >> 16;
+                    const int j0 = NEAR_R + (k - 1) * LCH;
+                    uint32_t facc = (uint32_t)__umul24(fs, (uint32_t)j0) + (1u << (RFIX - 1));
+                    int aj = base0 + __mul24(j0, cj) + cnt_lds;
 #pragma unroll
                     for (int u = 0; u < LCH; ++u) {
                         fld8_add(aj + __mul24((int)(facc >> RFIX), cm), 1u);
                         facc += fs; aj += cj;
                     }
-                } else {
-                    // rows: row = rx0 + j * rj + m * rm, where (rj, rm) = (+-1, 0) for a ray along x and (0, +-1) along y
-                    const int rj = (cj == 1 || cj == -1) ? 0 : (cj > 0 ? 1 : -1), rm = (cm == 1 || cm == -1) ? 0 : (cm > 0 ? 1 : -1);
-                    int rowj = rx0 + j0 * rj;
-#pragma unroll
-                    for (int u = 0; u < LCH; ++u) {
-                        const int m = (int)(facc >> RFIX);
-                        const bool in = (unsigned)(rowj + m * rm) < (unsigned)rows_w;
-                        const int c = in ? aj + __mul24(m, cm) : 4 * lane;                 // outside the strip: nothing added, a word of the lane's own
-                        atomicAdd(&cnt[c >> 2], in ? 1u << ((c & 3) * 8) : 0u);
-                        facc += fs; aj += cj; rowj += rj;
-                    }
-                }
+                } else strip_chunk(b, k);
             }
             // the partial chunk at the end of every ray with at least NEAR_R + 1 steps
             for (int b = tid; b < v.B; b += RB) {
