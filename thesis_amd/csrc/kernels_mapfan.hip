@@ -949,12 +949,8 @@ __global__ __launch_bounds__(FB) void map_update_fan_kernel(DevView v) {
 
 void launch_map_update_fan(const DevView& v, hipStream_t s) {
     const FanGeom g = fan_geom(v.B, v.reach);
-    static int lds_attr = 0;
-    if (g.bytes > lds_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(map_update_fan_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, g.bytes);
-        lds_attr = g.bytes;
-    }
+    static size_t lds_set[MAX_DEVICES] = {};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_fan_kernel), (size_t)g.bytes, lds_set);
     hipLaunchKernelGGL(map_update_fan_kernel, dim3(v.P), dim3(FB), (size_t)g.bytes, s, v);
 }
 

@@ -1357,12 +1357,8 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
 
 void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s) {
     const RayGeom g = ray_geom(v.B, v.reach);
-    static int lds_attr = 0;
-    if (g.bytes > lds_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(map_update_ray_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, g.bytes);
-        lds_attr = g.bytes;
-    }
+    static size_t lds_set[MAX_DEVICES] = {};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_ray_kernel), (size_t)g.bytes, lds_set);
     hipLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, v, only);
 }
 

@@ -718,12 +718,8 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v, cons
 
 void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s) {
     size_t lds = raycast_lds_bytes(v.B, v.reach);
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {   // more than the default 64 KiB of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(map_update_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
+    static size_t lds_set[MAX_DEVICES] = {};   // more than the default 64 KiB of dynamic LDS
+    ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_kernel), lds, lds_set);
     // the chain: every kernel leaves mu_fallback[p] != 0 for the particles it could not hold
     bool first = false;
     const bool ray_ok = map_update_ray_available(v);

@@ -929,11 +929,8 @@ int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs) {
 }
 
 static void launch_match(const DevView& v, const MatchArgs& a, int grid, size_t lds, hipStream_t s) {
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
+    static size_t lds_set[MAX_DEVICES] = {};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(match_kernel), lds, lds_set);
     hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, v, a);
 }
 
@@ -942,11 +939,8 @@ int ndt_cells(double mcs) { return (int)floor(0.1 / mcs + 0.5); }
 
 static void launch_ndt(const DevView& v, const MatchArgs& a, int grid, hipStream_t s) {
     size_t lds = ndt_lds_bytes(a.N, a.cap_sel);
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ndt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
+    static size_t lds_set[MAX_DEVICES] = {};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ndt_kernel), lds, lds_set);
     hipLaunchKernelGGL(ndt_kernel, dim3(grid), dim3(NBLOCK), lds, s, v, a);
 }
 

@@ -10,6 +10,19 @@
 
 namespace rbpf {
 
+// The dynamic-LDS limit of a kernel is a per-DEVICE attribute; a process may hold handles on several GPUs.  `set` is the
+// launcher's own table of what it has set so far (one entry per device).
+static const int MAX_DEVICES = 16;
+inline void ensure_dynamic_lds(const void* fn, size_t bytes, size_t* set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool tracked = dev >= 0 && dev < MAX_DEVICES;
+    if (tracked && bytes <= set[dev]) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (tracked) set[dev] = bytes;
+}
+
+
 static const int BLOCK = 256;          // 4 waves of 64
 static const int WIN = 128;            // LDS window edge (storage cells)
 static const int MAX_ITEMS_PER_PARTICLE = 64;
