@@ -714,37 +714,45 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 }
                 uint16_t* myev = evl + mykey * ECAP;
                 const int q0 = rpos[b];
-                for (int dir = 0; dir < 2 && act; ++dir) {                          // dir 0: b and the steeper slopes, dir 1: the flatter ones
-                    for (int q = dir ? q0 - 1 : q0; dir ? q >= cst : q < cen; q += dir ? -1 : 1) {
-                        const uint2 rr = srec[q];
-                        const uint32_t fs = rr.x & 0xFFFFFFu;
-                        const int dmaj_r = (int)(rr.y & 0xFFFFu), rb = (int)(rr.y >> 16);
-                        const int mg = (int)((fs * (uint32_t)dmaj_b + (1u << (RFIX - 1))) >> RFIX);
-                        if (dir ? mg < lo : mg > hi) break;                         // sorted by slope: nothing further can reach the cell
+                // one candidate record: past the window (-> that direction is finished), or tested against the cell's sources
+                auto candidate = [&](const uint2 rr, const bool down, bool& finished) {
+                    const uint32_t fs = rr.x & 0xFFFFFFu;
+                    const int dmaj_r = (int)(rr.y & 0xFFFFu), rb = (int)(rr.y >> 16);
+                    const int mg = (int)((fs * (uint32_t)dmaj_b + (1u << (RFIX - 1))) >> RFIX);
+                    if (down ? mg < lo : mg > hi) { finished = true; return; }      // sorted by slope: nothing further can reach the cell
 #pragma unroll
-                        for (int w = 0; w < 2; ++w) {
-                            const int jj = w ? cj2 : cj1;
-                            if (jj < 0 || jj > dmaj_r) continue;
-                            const int m = (int)((fs * (uint32_t)jj + (1u << (RFIX - 1))) >> RFIX);
-                            if (m != cc1 && m != cc2) continue;
-                            const int rem = dmaj_r - jj;
-                            const bool occ_r = (rr.x >> 24) & 1u, nearev = rem == 1 && ((rr.x >> 25) & 1u);
-                            const int rank = rem == 0 ? (occ_r ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
-                            if ((rank == EV_OCC && (rb << 1) < mykey) || (nearev && (rb << 1 | 1) < mykey)) { act = false; break; }
-                            if (nev + 2 > cap && cap == ECAP && !special) {                // the list is full: move to a long one
-                                slot = atomicAdd(&s_npool, 1);
-                                if (slot < NPOOL) {
-                                    uint16_t* const pl = pool + slot * PCAP;
-                                    for (int i = 0; i < nev; ++i) pl[i] = myev[i];
-                                    myev = pl; cap = PCAP;
-                                } else slot = -1;
-                            }
-                            if (nev < cap) myev[nev] = (uint16_t)(rb << 3 | rank);
-                            ++nev;
-                            if (nearev) { if (nev < cap) myev[nev] = (uint16_t)(rb << 3 | EV_NEAR); ++nev; }
+                    for (int w = 0; w < 2; ++w) {
+                        const int jj = w ? cj2 : cj1;
+                        if (jj < 0 || jj > dmaj_r) continue;
+                        const int m = (int)((fs * (uint32_t)jj + (1u << (RFIX - 1))) >> RFIX);
+                        if (m != cc1 && m != cc2) continue;
+                        const int rem = dmaj_r - jj;
+                        const bool occ_r = (rr.x >> 24) & 1u, nearev = rem == 1 && ((rr.x >> 25) & 1u);
+                        const int rank = rem == 0 ? (occ_r ? EV_OCC : EV_E_LAST) : rem == 1 ? EV_E_2 : rem == 2 ? EV_E_3 : EV_E_FAR;
+                        if ((rank == EV_OCC && (rb << 1) < mykey) || (nearev && (rb << 1 | 1) < mykey)) { act = false; return; }
+                        if (nev + 2 > cap && cap == ECAP && !special) {                    // the list is full: move to a long one
+                            slot = atomicAdd(&s_npool, 1);
+                            if (slot < NPOOL) {
+                                uint16_t* const pl = pool + slot * PCAP;
+                                for (int i = 0; i < nev; ++i) pl[i] = myev[i];
+                                myev = pl; cap = PCAP;
+                            } else slot = -1;
                         }
-                        if (!act) break;
+                        if (nev < cap) myev[nev] = (uint16_t)(rb << 3 | rank);
+                        ++nev;
+                        if (nearev) { if (nev < cap) myev[nev] = (uint16_t)(rb << 3 | EV_NEAR); ++nev; }
                     }
+                };
+                // both directions at once - b and the steeper slopes upwards, the flatter ones downwards: two independent
+                // record reads in flight per step, half the steps (the order of the events does not matter: they are sorted)
+                int qu = q0, qd = q0 - 1;
+                bool fu = qu >= cen, fd = qd < cst;
+                while (act && !(fu && fd)) {
+                    const uint2 ru = srec[fu ? q0 : qu], rd = srec[fd ? q0 : qd];
+                    if (!fu) candidate(ru, false, fu);
+                    if (act && !fd) candidate(rd, true, fd);
+                    ++qu; --qd;
+                    fu = fu || qu >= cen; fd = fd || qd < cst;
                 }
                 if (!act) pflag[mykey] = 0;
             }
