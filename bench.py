@@ -321,7 +321,7 @@ def main():
     bytes_pu = 8.0 * W_per_particle + 4.0 * args.beams * 2 + 208.0
     step_ach = bytes_pu * args.particles * world / (elapsed / args.steps) / 1e9
     n_fb = max(1, args.steps) * args.particles
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": dominant, "kernel_symbol": KERNEL_NAMES.get(dominant), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 # the same kernel in the bytes it actually moves (int8 cells; PMC FETCH/WRITE passes, profiles/)
                 "frac_stored_bytes": (traffic / (mean_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and mean_ms[dominant] > 0 else None,
