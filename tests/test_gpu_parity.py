@@ -505,6 +505,36 @@ def test_map_update_extreme_beam_counts(eng_mod, B):
     e.close()
 
 
+@pytest.mark.parametrize("B,cs", [(1081, 0.05), (1200, 0.015625)])
+def test_map_update_many_long_beams_in_strips(eng_mod, map_kernel, B, cs):
+    """Beams of 14.9 m all round: a 600-cell fan at 0.05 m and a 1900-cell one at 1/64 m - several strips of the
+    global-index kernel.  At 1/64 m the 1200 rays have more than 65 535 whole 16-step chunks, so the strips walk level by
+    level instead of through 16-bit item prefixes.  Second scan: 11 m.  Cell-exact against the C oracle; no particle reaches
+    the window kernel by default."""
+    from oracle import c_oracle
+    ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
+    rng = np.random.Generator(np.random.PCG64(123))
+    pose = np.array([[0.313, -0.227, 0.5]])
+    e = eng_mod.ParticleEngine(1, max_beams=B, cell_size=cs, pool_tiles=12)
+    lib = c_oracle.load()
+    m = c_oracle.CMap(lib, cs)
+    for r in (14.9 + rng.normal(0, 0.01, B), 11.0 + 0.5 * np.sin(7 * ang)):
+        e.set_scan(r, ang)
+        e.map_update(pose)
+        sx, sy = orc.scan_xy(r, ang)
+        m.update(pose[0], sx, sy)
+    want = {c: np.rint(t / Q).astype(np.int8) for c, t in m.tiles().items()}
+    got = dict(e.tiles(0))
+    assert set(got) == set(want)
+    for c in want:
+        assert np.array_equal(got[c], want[c]), f"tile {c}: {int(np.count_nonzero(got[c] != want[c]))} cells differ"
+    c = e.counters()
+    assert c["ray_cells_visited"] == lib.orc_map_cells_visited(m.h)
+    if map_kernel == "auto":
+        assert c["window_fallbacks"] == 0 and c["map_windows"] >= 2 * 2           # at least two strips per scan
+    e.close()
+
+
 @pytest.mark.xfail(strict=True, reason="device sincos vs libm: the last bit decides the cell of an end point that lies exactly on a cell boundary")
 def test_map_update_on_a_lattice_line_known_deviation(eng_mod):
     """The documented carve-out of the map-update parity (parity notes), with the inputs that first showed it
