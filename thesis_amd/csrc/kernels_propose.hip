@@ -86,6 +86,38 @@ struct ProposeArgs {
 
 static const int WCH = 32;              // samples weighted per pass over the beams
 
+// The proposal frame of a particle - eigen-decomposition of the matcher covariance, pseudo-inverse square root U, sampling
+// matrix A, log normalisation - is a long SERIAL computation (a few thousand float64 instructions).  One thread per
+// particle in a kernel of its own: 64 particles share the instruction stream that one lane of the weighting kernel's
+// first wave used to run alone (a third of that kernel's instructions).
+static const int PREP_W = 24;       // doubles per particle: U[9], A[9], mean[3], log c, bad, -
+__global__ __launch_bounds__(64) void propose_prep_kernel(DevView v, ProposeArgs a) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= v.P) return;
+    const double* m = a.match + (size_t)(a.match_of ? a.match_of[p] : p) * 13;
+    double* o = v.prop_prep + (size_t)p * PREP_W;
+    bool bad = false;
+    for (int i = 0; i < 9; ++i) bad |= isnan(m[3 + i]);            // robot.py:73
+    a.bad[p] = bad ? 1 : 0;
+    o[22] = bad ? 1.0 : 0.0;
+    if (bad) return;
+    double w[3], V[3][3];
+    eig3_sym(m + 3, w, V);
+    // scipy.stats._multivariate._PSD: eps = 1e6 * eps_f64 * max|eig|; pseudo-inverse, pseudo-determinant
+    double mx = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
+    double eps = 1e6 * 2.220446049250313e-16 * mx;
+    double log_pdet = 0.0; int rank = 0;
+    for (int j = 0; j < 3; ++j) {
+        bool keep = w[j] > eps;
+        double inv_sqrt = fabs(w[j]) > eps ? sqrt(1.0 / w[j]) : 0.0;
+        if (keep) { log_pdet += log(w[j]); ++rank; }
+        double sq = w[j] > 0 ? sqrt(w[j]) : 0.0;
+        for (int i = 0; i < 3; ++i) { o[3 * i + j] = V[i][j] * inv_sqrt; o[9 + 3 * i + j] = V[i][j] * sq; }
+    }
+    o[18] = m[0]; o[19] = m[1]; o[20] = m[2];
+    o[21] = -0.5 * ((double)rank * 1.8378770664093453 + log_pdet);   // log(2*pi)
+}
+
 __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
     __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
     __shared__ int s_sum[KMAX];
@@ -93,33 +125,15 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     __shared__ int s_tab[49];
     __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
     __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
+    __shared__ double s_mom[16];                       // moments: mean[3], norm, sig[9], min_w
     __shared__ int s_bad;
     const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
     const int LL = v.L * v.L;
-    const double* m = a.match + (size_t)(a.match_of ? a.match_of[p] : p) * 13;
-
-    if (tid == 0) {
-        bool bad = false;
-        for (int i = 0; i < 9; ++i) bad |= isnan(m[3 + i]);            // robot.py:73
-        s_bad = bad;
-        a.bad[p] = bad ? 1 : 0;
-        if (!bad) {
-            double w[3], V[3][3];
-            eig3_sym(m + 3, w, V);
-            // scipy.stats._multivariate._PSD: eps = 1e6 * eps_f64 * max|eig|; pseudo-inverse, pseudo-determinant
-            double mx = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
-            double eps = 1e6 * 2.220446049250313e-16 * mx;
-            double log_pdet = 0.0; int rank = 0;
-            for (int j = 0; j < 3; ++j) {
-                bool keep = w[j] > eps;
-                double inv_sqrt = fabs(w[j]) > eps ? sqrt(1.0 / w[j]) : 0.0;
-                if (keep) { log_pdet += log(w[j]); ++rank; }
-                double sq = w[j] > 0 ? sqrt(w[j]) : 0.0;
-                for (int i = 0; i < 3; ++i) { s_U[i][j] = V[i][j] * inv_sqrt; s_A[i][j] = V[i][j] * sq; }
-            }
-            s_logc = -0.5 * ((double)rank * 1.8378770664093453 + log_pdet);   // log(2*pi)
-            s_mean[0] = m[0]; s_mean[1] = m[1]; s_mean[2] = m[2];
-        }
+    {   // the frame propose_prep_kernel left
+        const double* pr = v.prop_prep + (size_t)p * PREP_W;
+        if (tid < 9) { s_U[tid / 3][tid % 3] = pr[tid]; s_A[tid / 3][tid % 3] = pr[9 + tid]; }
+        if (tid < 3) s_mean[tid] = pr[18 + tid];
+        if (tid == 0) { s_logc = pr[21]; s_bad = pr[22] != 0.0; }
     }
     const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
     for (int i = tid; i < LL; i += BLOCK) {
@@ -167,7 +181,15 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     //      lies more than WSAFE (1e-3 for dim <= 1024, else 2e-3) inside its cell on both axes: the cell index is then the
     //      reference's (gridmap.py:119-128 on the float64 point).  The other 0.4 - 0.8 % of the look-ups are redone in
     //      float64 the reference's way (lookup_cell_home) once the beam's fast ones are out. -------------------------
-    const int8_t* const hbase = home.ok ? home.base : v.pool;
+    // (the home tile's address is the same for the whole workgroup: kept in scalar registers, so that a look-up is a
+    // 32-bit offset from a scalar base - no 64-bit address arithmetic per load)
+    typedef __attribute__((address_space(1))) const int8_t global_i8;
+    const global_i8* hbase;
+    {
+        const unsigned long long hb = (unsigned long long)(home.ok ? home.base : v.pool);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hb), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hb >> 32));
+        hbase = (const global_i8*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    }
     const float WSAFE = v.dim <= 1024 ? 1e-3f : 2e-3f;
     const bool f32_ok = home.ok && v.dim <= 2048;
     for (int k0 = 0; k0 < K; k0 += WCH) {
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
 #pragma unroll
             for (int kb = 0; kb < WCH; kb += 8) {
                 if (k0 + kb >= K) break;                              // uniform
-                int addr[8]; bool fast[8];
+                uint32_t addr[8]; bool fast[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool live = k0 + kb + u < K;
@@ -192,8 +214,9 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
                     const float fx = floorf(cx), fy = floorf(cy);
                     const int ix = (int)fx, iy = (int)fy;
                     const float rx = cx - fx, ry = cy - fy;
-                    fast[u] = beam_ok && live && fminf(rx, ry) > WSAFE && fmaxf(rx, ry) < 1.0f - WSAFE && max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim;
-                    addr[u] = fast[u] ? (int)__umul24(ix, v.dim) + iy : 0;
+                    // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
+                    fast[u] = (beam_ok & live) & (fminf(rx, ry) > WSAFE) & (fmaxf(rx, ry) < 1.0f - WSAFE) & (max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim);
+                    addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
                     if (live && !fast[u]) redo |= 1u << (kb + u);
                 }
                 int val[8];
@@ -232,30 +255,35 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     }
     __syncthreads();
 
-    // ---- moments, sequential in the reference's order (robot.py:89-114) --------------------------------
-    if (tid == 0) {
-        double min_w = s_w[0];
-        for (int k = 1; k < K; ++k) min_w = fmin(min_w, s_w[k]);
-        double mean[3] = {0, 0, 0}, norm = 0.0;
-        for (int k = 0; k < K; ++k) {
-            double kw = (s_w[k] - min_w) + 1e-2;
-            s_w[k] = kw;
-            for (int i = 0; i < 3; ++i) mean[i] = mean[i] + s_g[k][i] * kw;
-            norm = norm + kw;
+    // ---- moments (robot.py:89-114): every accumulator is a sequential float64 sum over the K samples in the reference's
+    //      order; the 13 accumulators are independent of each other, so each gets a lane ------------------------------
+    if (tid < 64) {
+        double mw = tid < K ? s_w[tid] : 1.7976931348623157e308;                   // min over the samples (any order)
+        for (int off = 32; off > 0; off >>= 1) mw = fmin(mw, __shfl_xor(mw, off, 64));
+        const double min_w = mw;
+        if (tid < K) s_w[tid] = (s_w[tid] - min_w) + 1e-2;                          // robot.py:96
+        __builtin_amdgcn_wave_barrier();
+        if (tid < 4) {                                                             // lanes 0-2: mean[i] * norm, lane 3: norm
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc = acc + (tid < 3 ? s_g[k][tid] * s_w[k] : s_w[k]);
+            s_mom[tid] = acc;
         }
-        for (int i = 0; i < 3; ++i) mean[i] = mean[i] / norm;
-        double sig[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (int k = 0; k < K; ++k) {
-            double d[3] = {s_g[k][0] + (-mean[0]), s_g[k][1] + (-mean[1]), s_g[k][2] + (-mean[2])};
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) sig[i][j] = sig[i][j] + (d[i] * d[j]) * s_w[k];
+        __builtin_amdgcn_wave_barrier();
+        const double norm = s_mom[3];
+        const double mean0 = s_mom[0] / norm, mean1 = s_mom[1] / norm, mean2 = s_mom[2] / norm;
+        if (tid < 9) {                                                             // lane 3 i + j: sig[i][j]
+            const int i = tid / 3, j = tid % 3;
+            const double mi = i == 0 ? mean0 : i == 1 ? mean1 : mean2, mj = j == 0 ? mean0 : j == 1 ? mean1 : mean2;
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc = acc + ((s_g[k][i] + (-mi)) * (s_g[k][j] + (-mj))) * s_w[k];
+            v.cov[(size_t)tid * v.P + p] = acc / norm;                             // robot.py:107,110
         }
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) v.cov[(size_t)(3 * i + j) * v.P + p] = sig[i][j] / norm;   // robot.py:107,110
-        norm = norm + min_w * (double)K;                               // robot.py:108
-        v.px[p] = mean[0]; v.py[p] = mean[1]; v.pth[p] = mean[2];      // robot.py:111-113
-        v.weight[p] = norm + v.weight[p];                              // robot.py:114
-        v.upd_pose[p] = mean[0]; v.upd_pose[v.P + p] = mean[1]; v.upd_pose[2 * v.P + p] = mean[2];   // robot.py:115
+        if (tid == 0) {
+            const double total = norm + min_w * (double)K;                         // robot.py:108
+            v.px[p] = mean0; v.py[p] = mean1; v.pth[p] = mean2;                    // robot.py:111-113
+            v.weight[p] = total + v.weight[p];                                     // robot.py:114
+            v.upd_pose[p] = mean0; v.upd_pose[v.P + p] = mean1; v.upd_pose[2 * v.P + p] = mean2;   // robot.py:115
+        }
     }
 }
 
@@ -269,6 +297,7 @@ __global__ __launch_bounds__(BLOCK) void bad_weight_kernel(DevView v, const uint
 void launch_propose_weight(const DevView& v, const double* d_match, const int32_t* d_match_of, const double* d_guesses, uint8_t* d_bad,
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s) {
     ProposeArgs a{d_match, d_match_of, d_guesses, d_bad, seed, stream, d_dbg_w};
+    hipLaunchKernelGGL(propose_prep_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, v, a);
     hipLaunchKernelGGL(propose_weight_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, a);
 }
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s) {

@@ -64,6 +64,7 @@ struct DevView {
     float *asel_x, *asel_y; int n_asel;  // beams with BF_MATCH_ADJ, compacted
     // per-update scratch
     double*  upd_pose;                 // [3][P] poses used by the current map update
+    double*  prop_prep;                // [P][24] proposal frame of the current scan update (kernels_propose.hip: U, A, mean, log c)
     int32_t* mu_fallback;              // [P] != 0: the map-update kernel that ran first gave the particle back to the next one
     int32_t* mu_hint;                  // [3][2] (attempts, geometry give-backs) of the whole-fan kernel's last launches, rotating by step
     int mu_step;                       // launch counter of the map update (selects the mu_hint slot)
