@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
                     const int ix = (int)fx, iy = (int)fy;
                     const float rx = cx - fx, ry = cy - fy;
                     // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
-                    fast[u] = (beam_ok & live) & (fminf(rx, ry) > WSAFE) & (fmaxf(rx, ry) < 1.0f - WSAFE) & (max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim);
+                    fast[u] = ((int)beam_ok & (int)live & (int)(fminf(rx, ry) > WSAFE) & (int)(fmaxf(rx, ry) < 1.0f - WSAFE) & (int)(max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim)) != 0;
                     addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
                     if (live && !fast[u]) redo |= 1u << (kb + u);
                 }
