@@ -524,12 +524,28 @@ enum { RS_PLAN = 1, RS_SRC2T = 2, RS_EXPAND = 4, RS_PAIR = 8, RS_GATHER = 16 };
 static const int RS_FUSE_MAX = 4096;        // beyond this the single workgroup costs more than the launches it saves
 struct FusedArgs { int stages; ResampleArgs ra; int32_t* idx; PairArgs pa; GatherArgs ga; };
 __global__ __launch_bounds__(PLAN_THREADS) void resample_fused_kernel(FusedArgs f) {
-    const int tid = threadIdx.x;
+    // T and the ancestor indices also live in LDS from the stage that makes them: the later stages search and chase them
+    // (a binary search per new particle, neighbour comparisons), which through global memory is a chain of L2 round trips
+    // in a kernel that runs on one CU while the others wait
+    extern __shared__ __align__(16) int32_t s_dyn[];                       // 2 * RS_FUSE_MAX words (dynamic: the stages' own arrays fill the static 64 KB)
+    int32_t* const s_T = s_dyn; int32_t* const s_idx = s_dyn + RS_FUSE_MAX;
+    const int tid = threadIdx.x, P = f.ra.P;
     if (f.stages & RS_PLAN) { resample_plan_stage(f.ra); __syncthreads(); }
-    if (f.stages & RS_SRC2T) { sources_to_T_stage(f.ra.P, f.idx, f.ra.T, f.ra.did); __syncthreads(); }
-    if (f.stages & RS_EXPAND) { for (int j = tid; j < f.ra.P; j += PLAN_THREADS) resample_expand_one(f.ra.P, f.ra.T, f.idx, j); __syncthreads(); }
-    if (f.stages & RS_PAIR) { resample_pair_stage(f.pa); __syncthreads(); }
-    if (f.stages & RS_GATHER) for (int j = tid; j < f.ga.P; j += PLAN_THREADS) resample_gather_one(f.ga, j);
+    if (f.stages & RS_SRC2T) { sources_to_T_stage(P, f.idx, f.ra.T, f.ra.did); __syncthreads(); }
+    for (int j = tid; j < P; j += PLAN_THREADS) s_T[j] = f.ra.T[j];
+    __syncthreads();
+    if (f.stages & RS_EXPAND) { for (int j = tid; j < P; j += PLAN_THREADS) { resample_expand_one(P, s_T, s_idx, j); f.idx[j] = s_idx[j]; } }
+    else for (int j = tid; j < P; j += PLAN_THREADS) s_idx[j] = f.idx[j];
+    __syncthreads();
+    if (f.stages & RS_PAIR) { PairArgs pa = f.pa; pa.T = s_T; pa.idx = s_idx; resample_pair_stage(pa); __syncthreads(); }
+    if (f.stages & RS_GATHER) { GatherArgs ga = f.ga; ga.T = s_T; ga.idx = s_idx; for (int j = tid; j < ga.P; j += PLAN_THREADS) resample_gather_one(ga, j); }
+}
+
+static void launch_resample_fused(const FusedArgs& f, hipStream_t s) {
+    const size_t lds = 2 * RS_FUSE_MAX * sizeof(int32_t);
+    static size_t lds_set[MAX_DEVICES] = {};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(resample_fused_kernel), lds, lds_set);
+    hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), lds, s, f);
 }
 
 void launch_export_weights(const DevView& v, double* d_out, int n_global, const uint8_t* d_bad, hipStream_t s) {
@@ -558,7 +574,7 @@ void launch_resample_indices(int P, const double* d_w, double u, double spread, 
     ResampleArgs ra{P, d_w, u, spread, d_T, d_did, d_err};
     if (P <= RS_FUSE_MAX) {
         FusedArgs f{RS_PLAN | RS_EXPAND, ra, d_idx, PairArgs{}, GatherArgs{}};
-        hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
+        launch_resample_fused(f, s);
         return;
     }
     hipLaunchKernelGGL(resample_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, ra);
@@ -575,7 +591,7 @@ void launch_resample_local(const DevView& v, const ResampleBuffers& b, const dou
     FusedArgs f{RS_PLAN | RS_EXPAND | RS_PAIR | RS_GATHER, ResampleArgs{v.P, d_w, u, spread, b.T, b.did, v.err}, b.idx,
                 PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
                 GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of}};
-    hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
+    launch_resample_fused(f, s);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
@@ -591,7 +607,7 @@ void launch_resample_apply_sources(const DevView& v, const ResampleBuffers& b, h
     FusedArgs f{RS_SRC2T | RS_PAIR | RS_GATHER, ResampleArgs{v.P, nullptr, 0.0, 0.0, b.T, b.did, v.err}, b.idx,
                 PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
                 GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of}};
-    hipLaunchKernelGGL(resample_fused_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, f);
+    launch_resample_fused(f, s);
     CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
