@@ -101,7 +101,8 @@ __host__ __device__ inline RayGeom ray_geom(int B, int reach) {
 // the flagged-cell pass borrows the counter window: 16-bit event counts, ECAP events per pair, the special list
 __host__ __device__ inline bool ray_lists_fit(const RayGeom& g) {
     const int npair = 2 * g.bpad;
-    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + npair * 2 + NPOOL * (PCAP * 2 + 4) + 64 <= g.ncell;   // + the sorted ray records, the list of pairs in play, the long lists
+    return npair * 2 + npair * ECAP * 2 + RSPEC * 2 + g.bpad * 8 + npair * 2 + NPOOL * (PCAP * 2 + 4) + 64 <= g.ncell &&   // + the sorted ray records, the list of pairs in play, the long lists
+           npair * 2 + npair * ECAP * 2 + RSPEC * 2 + (RB / 64) * 256 * 4 <= g.ncell;                                      // the bucket sort's key scratch in the records' place
 }
 
 bool map_update_ray_available(const DevView& v) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int key = 2 * tid + k, st = bkt_start(key), en = bkt_end(key);
-            if (en - st > 64) s_fb = 1;
+            if (en - st > 256) s_fb = 1;
             else if (en - st > 6) { const int pos = atomicAdd(&s_nspec, 1); if (pos < RSPEC) bigb[pos] = (uint16_t)key; else s_fb = 1; }
             else for (int i = st + 1; i < en; ++i) {
                 const int rb = brays[i];
@@ -574,14 +575,33 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
         for (int i = tid; i < npair / 4; i += RB) reinterpret_cast<uint32_t*>(pflag)[i] = 0;
         BAR_LDS();
         const int nbig = UNI(min(s_nspec, RSPEC));
+        uint32_t* const kscr = reinterpret_cast<uint32_t*>(bigb + RSPEC) + wave * 256;   // the wave's keys (behind the list of big buckets: the ray records are not built yet)
         for (int k = wave; k < nbig; k += RB / 64) {
-            const int key = bigb[k], st = bkt_start(key), n = bkt_end(key) - st;   // 7 .. 64 rays
+            const int key = bigb[k], st = bkt_start(key), n = bkt_end(key) - st;   // 7 .. 256 rays (more than 64: a wall right in front of the sensor)
             const uint32_t fbase = (uint32_t)(key % NBIN) << BIN_SHIFT;
-            const int rb = lane < n ? (int)brays[st + lane] : 0;
-            const uint32_t kf = lane < n ? ((r_fstep[rb] - fbase) << 12) | (uint32_t)rb : 0xFFFFFFFFu;
-            int rank = 0;
-            for (int e = 0; e < n; ++e) rank += (uint32_t)__shfl((int)kf, e, 64) < kf;          // keys are distinct (the beam is part of them)
-            if (lane < n) brays[st + rank] = (uint16_t)rb;                           // (every lane has read its own entry)
+            if (n <= 64) {
+                const int rb = lane < n ? (int)brays[st + lane] : 0;
+                const uint32_t kf = lane < n ? ((r_fstep[rb] - fbase) << 12) | (uint32_t)rb : 0xFFFFFFFFu;
+                int rank = 0;
+                for (int e = 0; e < n; ++e) rank += (uint32_t)__shfl((int)kf, e, 64) < kf;      // keys are distinct (the beam is part of them)
+                if (lane < n) brays[st + rank] = (uint16_t)rb;                       // (every lane has read its own entry)
+            } else {
+                int rb[4]; uint32_t kf[4]; int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int at = lane + 64 * i;
+                    rb[i] = at < n ? (int)brays[st + at] : 0;
+                    kf[i] = at < n ? ((r_fstep[rb[i]] - fbase) << 12) | (uint32_t)rb[i] : 0xFFFFFFFFu;
+                    if (at < n) kscr[at] = kf[i];
+                }
+                for (int e = 0; e < n; ++e) {
+                    const uint32_t ke = kscr[e];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rank[i] += ke < kf[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (lane + 64 * i < n) brays[st + rank[i]] = (uint16_t)rb[i];
+            }
         }
         BAR_LDS();
         if (tid == 0) s_nspec = 0;
