@@ -84,7 +84,6 @@ struct ProposeArgs {
     double* dbg_w;              // optional [P][K] raw sample weights (tests), or nullptr
 };
 
-static const int WCH = 32;              // samples weighted per pass over the beams
 
 // The proposal frame of a particle - eigen-decomposition of the matcher covariance, pseudo-inverse square root U, sampling
 // matrix A, log normalisation - is a long SERIAL computation (a few thousand float64 instructions).  One thread per
@@ -192,42 +191,42 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     }
     const float WSAFE = v.dim <= 1024 ? 1e-3f : 2e-3f;
     const bool f32_ok = home.ok && v.dim <= 2048;
-    for (int k0 = 0; k0 < K; k0 += WCH) {
-        int acc[WCH];
+    // Work split: four lanes share a beam, each takes eight of the (up to 32) samples; 64 beams per pass of the workgroup.
+    // 1081 beams are 17 passes with the last one 89 % full (a thread per beam and all samples: 5 passes, the last 22 %
+    // full), and the sums of a sample meet in the lanes that are four apart.
+    {
+        const int k0 = 8 * (tid & 3);                                 // this lane's samples k0 .. k0 + 7
+        int acc[8];
 #pragma unroll
-        for (int k = 0; k < WCH; ++k) acc[k] = 0;
-        for (int b = tid; b < v.B; b += BLOCK) {
+        for (int u = 0; u < 8; ++u) acc[u] = 0;
+        for (int b = tid >> 2; b < v.B && k0 < K; b += BLOCK / 4) {
             if (!(v.bflags[b] & BF_WEIGHT)) continue;                 // robot.py:130
             const double x = v.bx[b], y = v.by[b];
             const float x32 = (float)x, y32 = (float)y;
             const bool beam_ok = f32_ok && (fabsf(x32) + fabsf(y32)) * (float)inv_cs <= 1.5f * (float)v.dim;   // the error budget's premise
             uint32_t redo = 0;
+            uint32_t addr[8]; bool fast[8];
 #pragma unroll
-            for (int kb = 0; kb < WCH; kb += 8) {
-                if (k0 + kb >= K) break;                              // uniform
-                uint32_t addr[8]; bool fast[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool live = k0 + kb + u < K;
-                    const float4 q = s_q[min(k0 + kb + u, K - 1)];
-                    const float cx = fmaf(q.x, x32, fmaf(-q.y, y32, q.z)), cy = fmaf(q.y, x32, fmaf(q.x, y32, q.w));   // lidar.py:123, in cells
-                    const float fx = floorf(cx), fy = floorf(cy);
-                    const int ix = (int)fx, iy = (int)fy;
-                    const float rx = cx - fx, ry = cy - fy;
-                    // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
-                    fast[u] = ((int)beam_ok & (int)live & (int)(fminf(rx, ry) > WSAFE) & (int)(fmaxf(rx, ry) < 1.0f - WSAFE) & (int)(max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim)) != 0;
-                    addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
-                    if (live && !fast[u]) redo |= 1u << (kb + u);
-                }
-                int val[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) val[u] = hbase[addr[u]];
-                // (the empty statement keeps the eight loads together: the compiler would otherwise sink each into the
-                // select that uses it and wait for it there, one load at a time)
-                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[kb + u] += fast[u] ? val[u] : 0;
+            for (int u = 0; u < 8; ++u) {
+                const bool live = k0 + u < K;
+                const float4 q = s_q[min(k0 + u, K - 1)];
+                const float cx = fmaf(q.x, x32, fmaf(-q.y, y32, q.z)), cy = fmaf(q.y, x32, fmaf(q.x, y32, q.w));   // lidar.py:123, in cells
+                const float fx = floorf(cx), fy = floorf(cy);
+                const int ix = (int)fx, iy = (int)fy;
+                const float rx = cx - fx, ry = cy - fy;
+                // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
+                fast[u] = ((int)beam_ok & (int)live & (int)(fminf(rx, ry) > WSAFE) & (int)(fmaxf(rx, ry) < 1.0f - WSAFE) & (int)(max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim)) != 0;
+                addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
+                if (live && !fast[u]) redo |= 1u << u;
             }
+            int val[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) val[u] = hbase[addr[u]];
+            // (the empty statement keeps the eight loads together: the compiler would otherwise sink each into the
+            // select that uses it and wait for it there, one load at a time)
+            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += fast[u] ? val[u] : 0;
             while (redo) {                                            // float64, the reference's operations
                 const int k = k0 + __ffs(redo) - 1;
                 redo &= redo - 1;
@@ -238,12 +237,10 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
             }
         }
 #pragma unroll
-        for (int k = 0; k < WCH; ++k) {
-            if (k0 + k < K) {
-                int s = acc[k];
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-                if ((tid & 63) == 0) atomicAdd(&s_sum[k0 + k], s);
-            }
+        for (int u = 0; u < 8; ++u) {
+            int s = acc[u];
+            for (int off = 32; off >= 4; off >>= 1) s += __shfl_xor(s, off, 64);      // the lanes with the same samples
+            if ((tid & 63) < 4 && k0 + u < K) atomicAdd(&s_sum[k0 + u], s);
         }
     }
     __syncthreads();
