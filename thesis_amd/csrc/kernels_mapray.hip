@@ -624,15 +624,12 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     // In the frame of the beam's class a storage cell's global source cells are the major steps {j1, j2} x the minor
     // offsets {c1, c2} (the second of each only where the index map repeats a cell); a ray of the class crosses the cell
     // iff minor(j) is c1 or c2 for one of those j it reaches.
-    // Pairs in play, listed in the order of perm (rays by falling length): the lanes of a wave then scan windows of
-    // similar width (a window holds ~ 1/j of a class's rays), so that few lanes wait for a long scan.
+    // Pairs in play, listed in beam order: neighbouring beams end on the same surface at similar distances, so the lanes
+    // of a wave scan windows of similar width and read neighbouring records.
     {
-        const int n1 = UNI(s_nk[1]);                                               // rays in perm; the shorter ones follow in beam order
-        for (int i0 = 0; i0 < n1 + v.B; i0 += RB) {                                // wave-uniform trip count (ballot)
+        for (int i0 = 0; i0 < v.B; i0 += RB) {                                     // wave-uniform trip count (ballot)
             const int i = i0 + tid;
-            int b = -1;
-            if (i < n1) b = perm[i];
-            else if (i - n1 < v.B && ((int)r_dmaj[i - n1] + 1 - NEAR_R) / LCH < 1) b = i - n1;
+            const int b = i < v.B ? i : -1;
             bool play[2] = {false, false};
             if (b >= 0 && (r_info[b] & (RI_VALID | RI_OCC)) == (RI_VALID | RI_OCC)) {
                 // a smaller pair of the neighbouring beams on the same global cell: this one cannot be the owner (the other
