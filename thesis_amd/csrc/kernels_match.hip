@@ -58,6 +58,7 @@ struct MatchArgs {
     const float* sel_x; const float* sel_y; int n_sel;   // selected beams / curr points, sensor frame, metres
     int n_coarse_rot;           // rotations on each side at the coarse level
     int cap_sel;                // LDS capacity for selected beams
+    int sc_cap;                 // entries of the score table in LDS (the coarse level runs in groups of rotations that fit)
     double cell_off;            // 0.5 in the stateless twin: its points are snapped to cell corners (hybridmap.py:226-227)
     int ndt;                    // 0 off; 1 matchScanCustom.m:38-44 acceptance; 2 take every valid NDT pose (diagnostic)
     int ndt_nc;                 // NDT cell edge in matcher cells (0.1 m, matchScanCustom.m:37); < 2: no cell can hold 3 points
@@ -71,7 +72,6 @@ struct MatchLds {
     uint32_t* occ;      // [N][N/32]
     uint32_t* dil;      // [N][N/32]
     uint32_t* crs;      // [N/4][words]
-    float* bx; float* by;   // [nb] selected beams in matcher-cell units
     float* fx4; float* fy4; // [ceil(nb/4) padded to 4] every 4th beam (fine level), contiguous
     float* cx8; float* cy8; // [ceil(nb/8) padded to 4] every 8th beam (coarse level), contiguous
     int* sc;            // [n coarse candidates] then reused for fine
@@ -81,13 +81,26 @@ struct MatchLds {
 // 8 neighbouring columns lie inside ONE word
 __host__ __device__ inline int match_crs_words(int N) { return ((N / M_COARSE) + 15) / 16; }
 
-size_t match_lds_bytes(int N, int B, int n_coarse) {
+// LDS of a match problem without its score table: occupancy + dilation bitmasks, the coarse map, the decimated beams
+static size_t match_lds_base(int N, int B) {
     size_t words = (size_t)N * (N / 32);
-    int fine = (2 * M_FINE_R + 1) * (2 * M_FINE_T + 1) * (2 * M_FINE_T + 1);
-    size_t nsc = (size_t)(n_coarse > fine ? n_coarse : fine);
     size_t dec = (size_t)(((B + 3) / 4 + 7) & ~3) + (size_t)(((B + 7) / 8 + 7) & ~3);
-    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + (size_t)((B + 3) & ~3) * 8 + dec * 8 + nsc * 4 + 256;
+    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + dec * 8 + 256;
 }
+// The score table holds the coarse candidates of as many rotations as fit when TWO workgroups share a CU's 160 KB (the
+// kernel's instruction stream keeps one workgroup's eight waves busy half of the time), at least one rotation's
+// (`per_rot`) and the fine level's; the coarse level runs in groups of rotations.
+size_t match_lds_bytes(int N, int B, int n_coarse, int per_rot) {
+    const size_t fine = (size_t)(2 * M_FINE_R + 1) * (2 * M_FINE_T + 1) * (2 * M_FINE_T + 1);
+    const size_t base = match_lds_base(N, B), two_wg = (160 * 1024) / 2 - 2048;      // 2 KB: the kernel's static LDS
+    size_t nsc = (size_t)n_coarse;
+    if (base + nsc * 4 > two_wg) nsc = base < two_wg ? (two_wg - base) / 4 : 0;
+    if (nsc < (size_t)per_rot) nsc = (size_t)per_rot;
+    if (nsc < fine) nsc = fine;
+    if (nsc > (size_t)n_coarse && (size_t)n_coarse >= fine) nsc = (size_t)n_coarse;
+    return base + nsc * 4;
+}
+int match_sc_capacity(int N, int B, size_t lds) { return (int)((lds - match_lds_base(N, B)) / 4); }
 
 __device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w) {
     if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0;
@@ -128,10 +141,8 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     s.occ = reinterpret_cast<uint32_t*>(smem);
     s.dil = s.occ + (size_t)N * W;
     s.crs = s.dil + (size_t)N * W;
-    s.bx = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N));
-    const int capb = (a.cap_sel + 3) & ~3, cap4 = ((a.cap_sel + 3) / 4 + 7) & ~3, cap8 = ((a.cap_sel + 7) / 8 + 7) & ~3;
-    s.by = s.bx + capb;
-    s.fx4 = s.by + capb; s.fy4 = s.fx4 + cap4;
+    const int cap4 = ((a.cap_sel + 3) / 4 + 7) & ~3, cap8 = ((a.cap_sel + 7) / 8 + 7) & ~3;
+    s.fx4 = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N)); s.fy4 = s.fx4 + cap4;
     s.cx8 = s.fy4 + cap4; s.cy8 = s.cx8 + cap8;
     s.sc = reinterpret_cast<int*>(s.cy8 + cap8);
     __shared__ double s_g[3], s_rng[2];
@@ -324,7 +335,6 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     {
         const float inv = (float)(1.0 / a.mcs);
         const float FAR = -1.0e6f;                          // padding beams fall outside the region: no hit
-        for (int b = tid; b < a.n_sel; b += MBLOCK) { s.bx[b] = a.sel_x[b] * inv; s.by[b] = a.sel_y[b] * inv; }
         for (int i = tid; i < cap4; i += MBLOCK) { const int b = 4 * i; const bool ok = b < a.n_sel; s.fx4[i] = ok ? a.sel_x[b] * inv : FAR; s.fy4[i] = ok ? a.sel_y[b] * inv : FAR; }
         for (int i = tid; i < cap8; i += MBLOCK) { const int b = 8 * i; const bool ok = b < a.n_sel; s.cx8[i] = ok ? a.sel_x[b] * inv : FAR; s.cy8[i] = ok ? a.sel_y[b] * inv : FAR; }
         if (tid == 0) s_nb = a.n_sel;
@@ -389,9 +399,10 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     const int kty = (int)ceil(ryc / M_COARSE) - 1;
     const int ntx = 2 * max(ktx, 0) + 1, nty = 2 * max(kty, 0) + 1;
     const int nr = 2 * a.n_coarse_rot + 1;
-    const int n_coarse = nr * ntx * nty;
-    for (int i = tid; i < n_coarse; i += MBLOCK) s.sc[i] = 0;           // candidate sums are accumulated with atomics
-    __syncthreads();
+    const int per_rot = ntx * nty;
+    // the score table holds the candidates of RG rotations: the coarse level runs in groups of rotations (the table of all
+    // 57 x 81 candidates would keep a second workgroup off the CU)
+    const int RG = max(1, min(nr, a.sc_cap / per_rot));
 
     MSTAMP(2);
     // Neighbouring translation candidates along y are consecutive bits of one mask row, so one LDS read scores a whole
@@ -403,11 +414,17 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     // ---- coarse level -------------------------------------------------------------------------------------------
     // work item = (rotation, beam slice): a beam is rotated once and looked up for every x translation (a shift by whole
     // coarse cells) and, through the byte lanes, for 8 y translations per LDS read; slices add their sums with atomics
+    int g_best = INT_MIN, g_key = INT_MAX;                               // best score so far and its tie-break key (uniform)
+    for (int r0 = 0; r0 < nr; r0 += RG) {
+    const int nrg = min(RG, nr - r0), n_coarse = nrg * per_rot;
+    for (int i = tid; i < n_coarse; i += MBLOCK) s.sc[i] = 0;           // candidate sums are accumulated with atomics
+    if (tid == 0) { s_best = INT_MIN; s_bestc = INT_MAX; }
+    __syncthreads();
     {
         const int MAXTX = 7;
-        const int NSC = max(1, MBLOCK / nr), nb8 = (nb + 7) / 8, per = (nb8 + NSC - 1) / NSC;   // beams per slice
-        for (int item = tid; item < nr * NSC; item += MBLOCK) {
-            const int ir = item / NSC, sl = item % NSC;
+        const int NSC = max(1, MBLOCK / nrg), nb8 = (nb + 7) / 8, per = (nb8 + NSC - 1) / NSC;   // beams per slice
+        for (int item = tid; item < nrg * NSC; item += MBLOCK) {
+            const int irl = item / NSC, ir = r0 + irl, sl = item % NSC;
             float sn, cs;
             __sincosf(gthf + (float)((double)(ir - a.n_coarse_rot) * M_COARSE * a.d0), &sn, &cs);
             const int g_lo = sl * per, g_hi = min(nb8, g_lo + per);
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
 #pragma unroll
                 for (int t = 0; t < MAXTX; ++t) {
                     if (t0 + t >= ntx) continue;
-                    int* dst = s.sc + (ir * ntx + t0 + t) * nty + g0;
+                    int* dst = s.sc + (irl * ntx + t0 + t) * nty + g0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int val = (int)(((j < 4 ? accA[t] : accB[t]) >> (8 * (j & 3))) & 0xFFu);
@@ -458,18 +475,22 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         if ((tid & 63) == 0) atomicMax(&s_best, mx);
     }
     __syncthreads();
-    if (tid == 0) s_bestc = INT_MAX;
-    __syncthreads();
-    const int best_coarse = s_best;
-    for (int cnd = tid; cnd < n_coarse; cnd += MBLOCK) {
-        if (s.sc[cnd] == best_coarse) {
+    const int best_group = s_best;
+    for (int cl = tid; cl < n_coarse; cl += MBLOCK) {
+        if (s.sc[cl] == best_group) {
             // ties: the candidate closest to the guess, then the lowest index (deterministic)
+            const int cnd = r0 * per_rot + cl;                                   // index over all rotations
             const int ir = cnd / (ntx * nty), it = cnd % (ntx * nty);
             int dr = ir - a.n_coarse_rot, dx = it / nty - max(ktx, 0), dy = it % nty - max(kty, 0);
             int key = ((dr * dr + dx * dx + dy * dy) << 16) | cnd;
             atomicMin(&s_bestc, key);
         }
     }
+    __syncthreads();
+    if (best_group > g_best || (best_group == g_best && s_bestc < g_key)) { g_best = best_group; g_key = s_bestc; }
+    __syncthreads();                                                     // (the next group resets the table and the two words)
+    }
+    if (tid == 0) s_bestc = g_key;
     __syncthreads();
     const int cbest = s_bestc & 0xFFFF;
     const int cir = cbest / (ntx * nty) - a.n_coarse_rot, cit = cbest % (ntx * nty);
@@ -567,9 +588,11 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         sincos(gth + bth, &snd, &csd);
         const float sn = (float)snd, cs = (float)csd;
         const float tx = fx + (float)(bdx / a.mcs), ty = fy + (float)(bdy / a.mcs);
+        const float inv1 = (float)(1.0 / a.mcs);
         int sc = 0;
         for (int b = tid; b < nb; b += MBLOCK) {
-            float ex = cs * s.bx[b] - sn * s.by[b] + tx, ey = sn * s.bx[b] + cs * s.by[b] + ty;
+            const float bxs = a.sel_x[b] * inv1, bys = a.sel_y[b] * inv1;   // (all beams: from global memory, the LDS holds the decimated sets)
+            float ex = cs * bxs - sn * bys + tx, ey = sn * bxs + cs * bys + ty;
             sc += field_hit(s, N, (int)floorf(ex), (int)floorf(ey));
         }
         for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off, 64);
@@ -927,8 +950,14 @@ int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs) {
     int k = (int)ceil(max_range_m / mcs / M_COARSE);
     return (2 * n_coarse_rot + 1) * (2 * k + 1) * (2 * k + 1);
 }
+int match_per_rot(double max_range_m, double mcs) {          // coarse candidates of one rotation, at most
+    int k = (int)ceil(max_range_m / mcs / M_COARSE);
+    return (2 * k + 1) * (2 * k + 1);
+}
 
-static void launch_match(const DevView& v, const MatchArgs& a, int grid, size_t lds, hipStream_t s) {
+static void launch_match(const DevView& v, const MatchArgs& a_in, int grid, size_t lds, hipStream_t s) {
+    MatchArgs a = a_in;
+    a.sc_cap = match_sc_capacity(a.N, a.cap_sel, lds);
     static size_t lds_set[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(match_kernel), lds, lds_set);
     hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, v, a);

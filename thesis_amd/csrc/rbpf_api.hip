@@ -261,7 +261,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, h->d_last_xy, 2 * (size_t)c.max_beams); ALLOC(h, h->d_tmp_sel, 2 * (size_t)c.max_beams);
         if (raycast_lds_bytes(c.max_beams, v.reach) > 160 * 1024) return fail(h, RBPF_EINVAL, "max_beams too large for the LDS window layout");
         match_geometry(c, c.cell_size, h->mN, h->mds, h->mmcs, h->md0, h->mncr);
-        h->mlds = match_lds_bytes(h->mN, c.max_beams, match_max_coarse(h->mncr, 0.7, h->mmcs));
+        h->mlds = match_lds_bytes(h->mN, c.max_beams, match_max_coarse(h->mncr, 0.7, h->mmcs), match_per_rot(0.7, h->mmcs));
         if (h->mlds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this cell_size");
         if (c.ndt_refine && ndt_cells(h->mmcs) >= 2) {         // the matcher hands its staged field to the NDT kernel
             if (ndt_lds_bytes(h->mN, c.max_beams) > 160 * 1024) return fail(h, RBPF_EINVAL, "NDT stage: matcher region does not fit in LDS");
@@ -672,7 +672,8 @@ int rbpf_match_scan(rbpf_handle* h, const double* curr_xy, int32_t n_curr, const
     ncr = (int)floor(fabs(pose_range3[2]) / (4 * d0));             // coarse rotation step = 4 * d0
     if (ncr * 4 * d0 >= fabs(pose_range3[2])) --ncr;
     if (ncr < 0) ncr = 0;
-    size_t lds = match_lds_bytes(N, h->cfg.max_beams, match_max_coarse(ncr, std::max(pose_range3[0], pose_range3[1]), mcs));
+    size_t lds = match_lds_bytes(N, h->cfg.max_beams, match_max_coarse(ncr, std::max(pose_range3[0], pose_range3[1]), mcs),
+                                 match_per_rot(std::max(pose_range3[0], pose_range3[1]), mcs));
     if (lds > 160 * 1024) return fail(h, RBPF_EINVAL, "matcher region does not fit in LDS for this resolution");
     std::vector<float> sel(2 * (size_t)h->cfg.max_beams, 0.f);
     for (int i = 0; i < n_curr; ++i) { sel[i] = (float)curr_xy[2 * i]; sel[h->cfg.max_beams + i] = (float)curr_xy[2 * i + 1]; }

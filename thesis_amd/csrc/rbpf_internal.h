@@ -177,7 +177,9 @@ struct UnpackJobHost { int32_t particle, pos, has, x0, x1, ya, yb, pad; long lon
 void launch_propose_weight(const DevView& v, const double* d_match, const int32_t* d_match_of, const double* d_guesses, uint8_t* d_bad,
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s);
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s);
-size_t match_lds_bytes(int N, int B, int n_coarse);
+size_t match_lds_bytes(int N, int B, int n_coarse, int per_rot);
+int match_sc_capacity(int N, int B, size_t lds);
+int match_per_rot(double max_range_m, double mcs);
 size_t ndt_lds_bytes(int N, int B);
 int ndt_cells(double mcs);
 void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot);
