@@ -104,12 +104,20 @@ typedef struct rbpf_counters {
     uint64_t ndt_accepted;        /* runs whose pose replaced the grid pose (matchScanCustom.m:39-41) */
     uint64_t match_shared;        /* particles that took the match result of an exact duplicate (a copy made by the
                                      last resample: same pose, covariance and map) instead of repeating the search */
-    uint64_t fallback_reasons;    /* why particles left the LDS-window map update: four 16-bit tallies (geometry /
-                                     index map, counter overflow check, event tables, replay lists)               */
+    uint64_t fallback_reasons;    /* why particles left the first map-update kernel, packed: three 16-bit tallies
+                                     (geometry / index map, counter bound, event tables), each SATURATING at 65535;
+                                     the exact tallies are fallback_geometry / _bound / _tables below             */
     double   ms_ndt;              /* HIP-event time of the last NDT-stage kernel                  */
     uint64_t stamp7;              /* eighth phase stamp of a -DRBPF_STAMPS diagnostic build, else 0 */
     uint64_t map_windows;         /* LDS windows the map update processed, summed over particles (1 per particle when
                                      the whole ray fan fits one window)                                            */
+    uint64_t fallback_geometry;   /* particles handed to the 128x128-window kernel: fan / index-map form / LDS rows  */
+    uint64_t fallback_bound;      /* ... the 8-bit hit fields could overflow (slope-bucket bound)                   */
+    uint64_t fallback_tables;     /* ... event tables full (global-index and whole-fan kernels)                     */
+    uint64_t map_events;          /* event-walk kernel: passes over cells that also got an occupied / nearby hit in
+                                     the same scan, found by the walk's returning adds, summed over particles       */
+    uint64_t map_event_overflows; /* ... particles whose list of such passes was full (every flagged cell of theirs
+                                     was then replayed by the exact membership test)                               */
 } rbpf_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -38,6 +38,8 @@ class RbpfCounters(C.Structure):
         ("reserved", C.c_uint64 * 7), ("window_fallbacks", C.c_uint64), ("ndt_runs", C.c_uint64), ("ndt_evaluations", C.c_uint64),
         ("ndt_accepted", C.c_uint64), ("match_shared", C.c_uint64),
         ("fallback_reasons", C.c_uint64), ("ms_ndt", C.c_double), ("stamp7", C.c_uint64), ("map_windows", C.c_uint64),
+        ("fallback_geometry", C.c_uint64), ("fallback_bound", C.c_uint64), ("fallback_tables", C.c_uint64),
+        ("map_events", C.c_uint64), ("map_event_overflows", C.c_uint64),
     ]
 
 

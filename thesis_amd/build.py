@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librbpf_hip.so")
-SOURCES = ["rbpf_api.hip", "kernels_weight.hip", "kernels_mapupdate.hip", "kernels_mapfan.hip", "kernels_mapray.hip", "kernels_state.hip",
+SOURCES = ["rbpf_api.hip", "kernels_weight.hip", "kernels_mapupdate.hip", "kernels_mapfan.hip", "kernels_mapray.hip", "kernels_mapev.hip", "kernels_state.hip",
            "kernels_propose.hip", "kernels_resample.hip", "kernels_match.hip", "kernels_inputs.hip"]
 HEADERS = ["rbpf_internal.h", "rbpf_math.h", "rbpf_device.h", "rbpf_mapupdate.h", os.path.join("..", "..", "include", "rbpf_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
@@ -29,6 +29,8 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    if not os.environ.get("RBPF_STAMPS") and any(os.path.exists(os.path.join(CSRC, s.replace(".hip", ".o.stamped"))) for s in SOURCES):
+        return True                                     # a diagnostic (stamped) object must not survive into a normal build
     return any(_newer(d, t) for d in deps)
 
 

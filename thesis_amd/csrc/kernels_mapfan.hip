@@ -30,7 +30,7 @@ namespace rbpf {
 // hand the particle to the window kernel (uniform over the workgroup; nothing has been written to the map yet);
 // the reason codes are tallied in a diagnostic counter: 1 geometry, 2 walk (8-bit guard, flagged-cell table),
 // 3 events, 4 replay lists
-#define GIVE_BACK(reason) do { if (tid == 0) { v.mu_fallback[p] = (reason); atomicAdd(&v.stats[ST_FALLBACK_REASONS], 1ull << (16 * ((reason) - 1))); } return; } while (0)
+#define GIVE_BACK(reason) do { if (tid == 0) { v.mu_fallback[p] = (reason); atomicAdd(&v.stats[(reason) == 1 ? ST_FALLBACK_REASONS : (reason) == 2 ? ST_FB_BOUND : ST_FB_TABLES], 1ull); } return; } while (0)
 
 static const int FB = 1024;                    // threads per particle
 static const int MINI_R = CHUNK - 1;           // cells with Chebyshev distance <= MINI_R from the start cell ...

@@ -35,7 +35,7 @@ namespace rbpf {
 
 // hand the particle to the window kernel (uniform over the workgroup; nothing has been written to the map yet);
 // reason codes: 1 geometry / index map, 2 counter bound, 3 event tables
-#define GIVE_BACK(reason) do { if (tid == 0) { v.mu_fallback[p] = (reason); atomicAdd(&v.stats[ST_FALLBACK_REASONS], 1ull << (16 * ((reason) - 1))); } return; } while (0)
+#define GIVE_BACK(reason) do { if (tid == 0) { v.mu_fallback[p] = (reason); atomicAdd(&v.stats[(reason) == 1 ? ST_FALLBACK_REASONS : (reason) == 2 ? ST_FB_BOUND : ST_FB_TABLES], 1ull); } return; } while (0)
 
 static const int RB = 1024;                    // threads per particle
 static const int NEAR_R = 16;                  // ray steps j < NEAR_R are counted in the 16-bit block

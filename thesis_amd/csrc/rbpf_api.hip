@@ -241,6 +241,9 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.stats, ST_COUNT); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
         ALLOC(h, v.mu_hint, 6); HIP_TRY(h, hipMemset(v.mu_hint, 0, 6 * 4));
+        v.ev_maxb = c.max_beams;
+        ALLOC(h, v.ev_scratch, P * map_update_ev_scratch_bytes(c.max_beams));
+        HIP_TRY(h, hipMemset(v.ev_scratch, 0, P * map_update_ev_scratch_bytes(c.max_beams)));
         ALLOC(h, h->d_did_early, 1);
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
@@ -250,7 +253,8 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
             // (and windows behind it), =chain runs all three in a row
             // before it (tests, comparisons); default: whole-fan kernel, global-index kernel for the fans it cannot hold
             const char* mk = getenv("RBPF_MAP_KERNEL");
-            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : (mk && std::string(mk) == "fan") ? 2 : (mk && std::string(mk) == "ray") ? 3 : (mk && std::string(mk) == "chain") ? 4 : 0;
+            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : (mk && std::string(mk) == "fan") ? 2 : (mk && std::string(mk) == "ray") ? 3 : (mk && std::string(mk) == "chain") ? 4 :
+                        (mk && std::string(mk) == "ev") ? 5 : 0;
             const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
             v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
             v.ndt_refine = h->cfg.ndt_refine;
@@ -429,7 +433,12 @@ int rbpf_get_counters(rbpf_handle* h, rbpf_counters* out) {
     c.match_shared = st[ST_MATCH_SHARED];
     for (int k = 0; k < 7; ++k) c.reserved[k] = st[8 + k];
     c.stamp7 = st[15];
-    c.fallback_reasons = st[ST_FALLBACK_REASONS];
+    {   // the packed form saturates per field; the exact tallies follow in their own fields
+        auto sat16 = [](unsigned long long x) { return x > 65535ull ? 65535ull : x; };
+        c.fallback_reasons = sat16(st[ST_FALLBACK_REASONS]) | (sat16(st[ST_FB_BOUND]) << 16) | (sat16(st[ST_FB_TABLES]) << 32);
+        c.fallback_geometry = st[ST_FALLBACK_REASONS]; c.fallback_bound = st[ST_FB_BOUND]; c.fallback_tables = st[ST_FB_TABLES];
+        c.map_events = st[ST_MAP_EVENTS]; c.map_event_overflows = st[ST_EV_OVERFLOWS];
+    }
     c.map_windows = st[ST_MAP_WINDOWS];
     if (h->profiling) {
         double* dst[5] = {&c.ms_raycast, &c.ms_weight, &c.ms_resample, &c.ms_match, &c.ms_ndt};

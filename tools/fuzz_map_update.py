@@ -14,7 +14,7 @@ bad = 0
 for case in range(N):
     cs = float(rng.choice([0.05, 0.05, 0.1, 0.025]))
     B = int(rng.choice([1, 7, 64, 180, 361, 721, 1081, 1081, 1500]))
-    kernel = os.environ.get("FUZZ_KERNEL") or str(rng.choice(["auto", "auto", "ray", "ray", "fan", "window"]))
+    kernel = os.environ.get("FUZZ_KERNEL") or str(rng.choice(["auto", "auto", "auto", "ray", "window"]))
     if kernel != "auto":
         os.environ["RBPF_MAP_KERNEL"] = kernel
     else:
@@ -88,5 +88,5 @@ for case in range(N):
     c = e.counters()
     e.close()
     if case % 20 == 0:
-        print("case", case, "ok so far, bad", bad, "cs", cs, "B", B, kernel, "fallbacks", c["window_fallbacks"], "reasons %x" % c["fallback_reasons"], "windows", c["map_windows"], flush=True)
+        print("case", case, "ok so far, bad", bad, "cs", cs, "B", B, kernel, "fallbacks", c["window_fallbacks"], "reasons %x" % c["fallback_reasons"], "windows", c["map_windows"], "events", c["map_events"], "ev overflows", c["map_event_overflows"], flush=True)
 print("done", N, "cases, mismatching:", bad)
