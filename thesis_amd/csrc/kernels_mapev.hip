@@ -2,24 +2,27 @@
 //
 // Same exact semantics as the other map kernels (kernels_mapupdate.hip has the ordered-replay argument).  Two kernels:
 //
-//   map_rays_kernel       256 threads per particle, several particles per CU.  Everything that is per beam and has little
-//                         parallelism inside one particle: pose, end cells (hybridmap.py:102-113), the closed form of the
-//                         reference's Bresenham per ray (32-bit fixed-point slope), tiles the rays enter (allocated here),
-//                         the fan's bounding box, the check of the index map's form, the 8-bit counter bound, the level
-//                         order of the rays.  Hands ~13 bytes per beam + a header to the second kernel through HBM scratch.
+//   map_rays_kernel       256 threads per particle, three particles per CU.  Everything that is per beam or per flagged
+//                         cell and has little parallelism inside one particle, so that its latencies overlap between
+//                         particles: pose, end cells (hybridmap.py:102-113), the closed form of the reference's
+//                         Bresenham per ray (32-bit fixed-point slope), the tiles the rays enter (allocated here), the
+//                         fan's bounding box, the check of the index map's form, the 8-bit counter bound, the level
+//                         order of the rays - and the RECORDS of the flagged cells: the cells that receive an "occupied"
+//                         / "nearby" hit in this scan (the only ones whose clamped adds do not commute) are grouped by
+//                         storage cell through an LDS hash table, every cell's few events are sorted by beam, its old
+//                         value is read.  ~13 bytes per beam, ~11 per flagged cell and a header go to the second kernel
+//                         through HBM scratch.
 //
 //   map_update_ev_kernel  1024 threads per particle, LDS window of 8-bit hit fields in GLOBAL cell-index space (as
-//                         kernels_mapray.hip: a ray step is pure arithmetic).  What is new: the cells that receive an
-//                         "occupied" / "nearby" hit (the only ones whose clamped adds do not commute) carry a flag bit
-//                         in their field before the walk starts, every add of the walk RETURNS the old field, and a step
+//                         kernels_mapray.hip: a ray step is pure arithmetic).  The flagged cells carry a flag bit in
+//                         their field before the walk starts, every add of the walk RETURNS the old field, and a step
 //                         that sees the flag appends (beam, step) to an event list - no slope buckets, no sort, no
 //                         gather.  Unflagged cells are written back from their counts as before.  After the write-back
-//                         the window's LDS is free: the flagged cells get a hash table (key = storage cell), their
-//                         occupied / nearby events are sorted by beam (a handful per cell), every listed pass is
-//                         counted into the interval between two such events that its beam falls into - all unoccupied
-//                         passes are the same clamped add, so only their NUMBER between consecutive occupied / nearby
-//                         events matters - and one lane folds emp^n0 . ev0 . emp^n1 . ev1 ... from the cell's old value
-//                         and stores the byte (and its occupancy bit).
+//                         the window's LDS is free: a hash table maps storage cells to records, every listed pass is
+//                         counted into the interval between two occupied / nearby events that its beam falls into - all
+//                         unoccupied passes are the same clamped add, so only their NUMBER between consecutive occupied
+//                         / nearby events matters - and one lane per record folds emp^n0 . ev0 . emp^n1 . ev1 ... from
+//                         the cell's old value and stores the byte (and its occupancy bit).
 //
 //   A beam's own last step (occupied) and the step before it (the pass that precedes its own "nearby" hit) are not
 //   walked at all: they are known without looking (the fold adds that pass in front of the beam's first event).
@@ -28,10 +31,16 @@
 
 namespace rbpf {
 
-#ifdef RBPF_STAMPS
+// diagnostic builds (RBPF_STAMPS=mapev): phase stamps of the main kernel, or with RBPF_STAMP_DEFS=-DSTAMP_PRE of the set-up kernel
+#if defined(RBPF_STAMPS) && !defined(STAMP_PRE)
 #define STAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#endif
+#if defined(RBPF_STAMPS) && defined(STAMP_PRE)
+#define PSTAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
 #endif
 
 static const int EB = 1024;                    // threads per particle, main kernel
@@ -43,36 +52,47 @@ static const int NBIN = 256;                   // slope buckets per direction cl
 static const int NB_WIN = NBIN / NEAR_R + 2;   // buckets that can hold the rays through one cell beyond the 16-bit block
 static const int HIT_BOUND = 62;               // per direction class; two classes can meet in a cell, +1 for the flag's count bit: 125 < 128
 static const int MAXLEV = 63;                  // whole 16-step chunks per ray (reach < 1000 cells)
-static const int EVCAP = 6144;                 // passes over flagged cells kept per particle (more: exact replay of every flagged cell)
+static const int EVCAP = 3072;                 // passes over flagged cells kept per particle (more: exact replay of every flagged cell)
 static const int HDR = 256;                    // header ints per particle in the scratch
-enum { H_STATUS = 0, H_X0, H_Y0, H_BXL, H_BXH, H_BYL, H_BYH, H_NLEV, H_CELLS, H_NK = 16, H_LP = 80 };   // H_NK[64], H_LP[65]
+enum { H_STATUS = 0, H_X0, H_Y0, H_BXL, H_BXH, H_BYL, H_BYH, H_NLEV, H_CELLS, H_NR, H_NEV, H_SLO, H_SHI, H_TLO, H_THI, H_A0, H_B0,
+       H_NK = 24, H_LP = 88 };                 // H_NK[64], H_LP[65]
 
-struct EvScratch { int bpad; size_t o_fs, o_end, o_nE, o_perm, o_info, stride; };
-__host__ __device__ inline EvScratch ev_scratch(int max_beams) {
+__host__ __device__ inline int ev_al16(int x) { return (x + 15) & ~15; }
+__host__ __device__ inline int ev_fanw(int reach) { return (2 * reach + 8 + 7) & ~7; }
+
+struct EvScratch { int bpad; size_t o_fs, o_end, o_nE, o_perm, o_info, o_gxb, o_gyb, o_rkey, o_rmeta, o_roldv, o_evs, stride; };
+__host__ __device__ inline EvScratch ev_scratch(int max_beams, int reach) {
     EvScratch s;
     s.bpad = (max_beams + 15) & ~15;
+    const size_t fanw = (size_t)ev_fanw(reach);
     size_t o = (size_t)HDR * 4;
-    s.o_fs = o;   o += (size_t)s.bpad * 4;
-    s.o_end = o;  o += (size_t)s.bpad * 4;
-    s.o_nE = o;   o += (size_t)s.bpad * 2;
-    s.o_perm = o; o += (size_t)s.bpad * 2;
-    s.o_info = o; o += (size_t)s.bpad;
+    s.o_fs = o;    o += (size_t)s.bpad * 4;
+    s.o_end = o;   o += (size_t)s.bpad * 4;
+    s.o_nE = o;    o += (size_t)s.bpad * 2;
+    s.o_perm = o;  o += (size_t)s.bpad * 2;
+    s.o_info = o;  o += (size_t)s.bpad;
+    s.o_gxb = o;   o += fanw;
+    s.o_gyb = o;   o += fanw;
+    s.o_rkey = o;  o += (size_t)s.bpad * 8;        // records: at most 2 per beam
+    s.o_rmeta = o; o += (size_t)s.bpad * 8;
+    s.o_roldv = o; o += (size_t)s.bpad * 2;
+    s.o_evs = o;   o += (size_t)s.bpad * 8;        // events + one more interval than events per record: at most 4 per beam, 16 bits
     s.stride = (o + 255) & ~(size_t)255;
     return s;
 }
-size_t map_update_ev_scratch_bytes(int max_beams) { return ev_scratch(max_beams).stride; }
+size_t map_update_ev_scratch_bytes(int max_beams, int reach) { return ev_scratch(max_beams, reach).stride; }
 
 struct EvGeom {
     int fanw, bpad, ncell, T, logT, E;
-    int o_mini, o_fs, o_end, o_nE, o_perm, o_info, o_oldv, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_evl, o_cnt;
-    int p_keys, p_cnta, p_offs, p_rep, p_evl, p_evs, p_ic, p_pslot, p_bytes;     // the window's LDS after the write-back
+    int o_mini, o_fs, o_end, o_nE, o_perm, o_info, o_gxb, o_gyb, o_gym, o_evl, o_cnt;
+    int p_keys, p_rec, p_evs, p_ic, p_bytes;                                      // the window's LDS after the write-back
+    int pre_keys, pre_cnt, pre_o2, pre_sh, pre_ux, pre_uy, pre_bytes;              // dynamic LDS of the set-up kernel
     int bytes;
     bool ok;
 };
-__host__ __device__ inline int ev_al16(int x) { return (x + 15) & ~15; }
 __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     EvGeom g;
-    g.fanw = (2 * reach + 8 + 7) & ~7;
+    g.fanw = ev_fanw(reach);
     g.bpad = (B + 3) & ~3;
     int o = 0;
     g.o_mini = o;  o += ev_al16(((NEAR_W * NEAR_W + 1) / 2) * 4);
@@ -81,9 +101,6 @@ __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     g.o_nE = o;    o += ev_al16(g.bpad * 2);
     g.o_perm = o;  o += ev_al16(g.bpad * 2);
     g.o_info = o;  o += ev_al16(g.bpad);
-    g.o_oldv = o;  o += ev_al16(g.bpad * 2);
-    g.o_ux = o;    o += ev_al16(g.fanw * 2);
-    g.o_uy = o;    o += ev_al16(g.fanw * 2);
     g.o_gxb = o;   o += ev_al16(g.fanw);
     g.o_gyb = o;   o += ev_al16(g.fanw);
     g.o_gym = o;   o += ev_al16(g.fanw + 16);
@@ -92,22 +109,26 @@ __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     const int avail = 160 * 1024 - 2560 - o - 64;      // 2.5 KB for the kernel's static LDS
     g.ncell = avail > 0 ? avail & ~127 : 0;
     g.bytes = o + g.ncell;
-    // after the write-back: hash table over the flagged storage cells (at most 2 B of them), their events, interval counts
+    // hash table over the flagged storage cells (at most 2 B of them)
     int T = 1024, lt = 10;
     while (T < 3 * g.bpad) { T <<= 1; ++lt; }
     g.T = T; g.logT = lt;
-    g.E = 4 * g.bpad;                                  // events (2 B) + one more interval than events per cell
+    g.E = 4 * g.bpad;                                  // events (<= 2 B) + one more interval than events per cell
     int q = 0;
-    g.p_keys = q;  q += T * 4;
-    g.p_cnta = q;  q += T * 4;
-    g.p_offs = q;  q += T * 4;
-    g.p_rep = q;   q += T * 2;
-    g.p_evl = q;   q += ev_al16(g.E * 2);
-    g.p_evs = q;   q += ev_al16(g.E * 2);
-    g.p_ic = q;    q += ev_al16(g.E * 2);
-    g.p_pslot = q; q += ev_al16(2 * g.bpad * 2);
+    g.p_keys = q; q += T * 4;
+    g.p_rec = q;  q += T * 2;
+    g.p_evs = q;  q += ev_al16(g.E * 2);
+    g.p_ic = q;   q += ev_al16(g.E * 2);
     g.p_bytes = q;
-    g.ok = g.ncell >= 24576 && g.p_bytes <= g.ncell && B <= 4095 && reach >= NEAR_R + 4 && reach < 1000;
+    q = 0;
+    g.pre_keys = q; q += T * 4;
+    g.pre_cnt = q;  q += T * 4;
+    g.pre_o2 = q;   q += T * 2;
+    g.pre_sh = q;   { const int a = 2 * 8 * NBIN * 2, b = ev_al16(g.E * 2); q += a > b ? a : b; }   // slope buckets, later the unsorted events
+    g.pre_ux = q;   q += ev_al16(g.fanw * 2);
+    g.pre_uy = q;   q += ev_al16(g.fanw * 2);
+    g.pre_bytes = q;
+    g.ok = g.ncell >= 24576 && g.p_bytes <= g.ncell && B <= 4095 && reach >= NEAR_R + 4 && reach < 1000 && g.pre_bytes <= 150 * 1024;
     return g;
 }
 
@@ -151,10 +172,32 @@ __device__ __forceinline__ uint32_t ev_min4(uint32_t n7, uint32_t satb, uint32_t
     return (satb & gem) | (n7 & ~gem);
 }
 
+// open addressing, linear probing, keys never ~0
+__device__ __forceinline__ int ev_hash_insert(uint32_t* keys, int T, int logT, uint32_t sc) {
+    uint32_t h = (sc * 2654435761u) >> (32 - logT);
+    for (;;) {
+        const uint32_t old = atomicCAS(&keys[h], 0xFFFFFFFFu, sc);
+        if (old == 0xFFFFFFFFu || old == sc) return (int)h;
+        h = (h + 1) & (uint32_t)(T - 1);                                         // (the table has more slots than there can be keys)
+    }
+}
+__device__ __forceinline__ int ev_hash_find(const uint32_t* keys, int T, int logT, uint32_t sc) {
+    uint32_t h = (sc * 2654435761u) >> (32 - logT);
+    for (int it = 0; it < T; ++it) {
+        const uint32_t k = keys[h];
+        if (k == sc) return (int)h;
+        if (k == 0xFFFFFFFFu) return -1;
+        h = (h + 1) & (uint32_t)(T - 1);
+    }
+    return -1;
+}
+
 // ================================================= set-up kernel =================================================
 __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const EvScratch SL = ev_scratch(v.ev_maxb);
+    const EvScratch SL = ev_scratch(v.ev_maxb, v.reach);
+    const EvGeom G = ev_geom(v.B, v.reach);
     unsigned char* const sp = v.ev_scratch + (size_t)p * SL.stride;
     int32_t* const hdr = reinterpret_cast<int32_t*>(sp);
     uint32_t* const o_fs = reinterpret_cast<uint32_t*>(sp + SL.o_fs);
@@ -162,17 +205,27 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
     uint16_t* const o_nE = reinterpret_cast<uint16_t*>(sp + SL.o_nE);
     uint16_t* const o_perm = reinterpret_cast<uint16_t*>(sp + SL.o_perm);
     uint8_t*  const o_info = sp + SL.o_info;
+    uint32_t* const keys = reinterpret_cast<uint32_t*>(smem + G.pre_keys);   // [T] flagged storage cells
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.pre_cnt);     // [T] events of the cell | fill pointer << 16
+    uint16_t* const o2 = reinterpret_cast<uint16_t*>(smem + G.pre_o2);       // [T] first event slot of the cell
+    uint16_t* const s_bins = reinterpret_cast<uint16_t*>(smem + G.pre_sh);   // [8 NBIN] rays per (class, slope bucket)
+    uint16_t* const s_far = s_bins + 8 * NBIN;                               // ... of the rays that reach the 8-bit fields
+    uint16_t* const evl = reinterpret_cast<uint16_t*>(smem + G.pre_sh);      // [E] events as they arrive (the buckets are done with by then)
+    uint16_t* const ux = reinterpret_cast<uint16_t*>(smem + G.pre_ux);       // U of global column fxl + i: every look-up below is an LDS read
+    uint16_t* const uy = reinterpret_cast<uint16_t*>(smem + G.pre_uy);
 
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4], s_fb, s_exact;
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1];
     __shared__ unsigned long long s_cells;
-    __shared__ __align__(16) uint16_t s_bins[8 * NBIN], s_far[8 * NBIN];
     __shared__ int s_wsum[PB / 64], s_wsum2[PB / 64];
 
     const int LL = v.L * v.L;
     const int KW = (v.dim + WIN - 1) / WIN;
     int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+#if defined(RBPF_STAMPS) && defined(STAMP_PRE)
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#endif
     const double s_px = v.upd_pose[p], s_py = v.upd_pose[v.P + p];
     double s_s, s_c;
     sincos(v.upd_pose[2 * v.P + p], &s_s, &s_c);                              // (every lane: the same instructions as one lane)
@@ -189,78 +242,113 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
     }
     if (tid == 0) { s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0; s_cells = 0; s_fb = 0; s_exact = 0; }
     for (int i = tid; i < LL; i += PB) { s_need[i] = 0; s_tab[i] = tab[i]; }
-    for (int i = tid; i < 8 * NBIN; i += PB) { s_bins[i] = 0; s_far[i] = 0; }
+    for (int i = tid; i < 8 * NBIN; i += PB) reinterpret_cast<uint32_t*>(s_bins)[i] = 0;     // both bucket arrays
+    for (int i = tid; i < G.T; i += PB) { keys[i] = 0xFFFFFFFFu; cnt[i] = 0; }
     if (tid <= MAXLEV) s_lcnt[tid] = 0;
+    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2;
+    for (int i = tid; i < G.fanw; i += PB) {
+        const int gxq = fxl + i, gyq = fyl + i;
+        const uint32_t ex = lut_valid_g(v, gxq) ? lut_at(v, gxq) : LUT_INVALID, ey = lut_valid_g(v, gyq) ? lut_at(v, gyq) : LUT_INVALID;
+        ux[i] = ex != LUT_INVALID ? (uint16_t)(lut_lat(ex) * v.dim + lut_cidx(ex)) : 0xFFFFu;
+        uy[i] = ey != LUT_INVALID ? (uint16_t)(lut_lat(ey) * v.dim + lut_cidx(ey)) : 0xFFFFu;
+    }
+    // this thread's first beams: their loads are in flight together
+    static const int NPRE = 5;
+    double pre_x[NPRE], pre_y[NPRE], pre_sc[NPRE]; int pre_f[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+        const int b = tid + i * PB;
+        pre_x[i] = b < v.B ? v.bx[b] : 0.0; pre_y[i] = b < v.B ? v.by[b] : 0.0; pre_sc[i] = b < v.B ? v.bscale[b] : 0.0; pre_f[i] = b < v.B ? (int)v.bflags[b] : 0;
+    }
     __syncthreads();
+    PSTAMP(0);
 
     const int C = v.R * v.dim + v.dim / 2;
-    auto U_of = [&](int g) { const uint32_t e = lut_at(v, g); return lut_lat(e) * v.dim + lut_cidx(e); };   // unrolled storage coordinate
-    auto lat_of = [&](int g) { return lut_lat(lut_at(v, g)); };                                            // biased lattice coordinate
-    const int a0 = UNI(lat_of(x0)), b0 = UNI(lat_of(y0));
-    {
-        unsigned long long my_cells = 0;
-        int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
-        for (int b = tid; b < v.B; b += PB) {
-            const double x = v.bx[b], y = v.by[b];
-            const int bf = (int)v.bflags[b];
-            double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
-            double gy = (s_s * x + s_c * y) + s_py;
-            int x1 = trunc_to_int(gx / v.cs), y1 = trunc_to_int(gy / v.cs);        // hybridmap.py:106
-            if (bf & BF_LONG) {                                                    // hybridmap.py:107-113
-                double sc = v.bscale[b];
-                x1 = trunc_to_int((double)x0 + sc * (double)(x1 - x0));
-                y1 = trunc_to_int((double)y0 + sc * (double)(y1 - y0));
-            }
-            int ddx = x1 - x0, ddy = y1 - y0;
-            if (ddx < -v.reach || ddx > v.reach || ddy < -v.reach || ddy > v.reach) {
-                atomicCAS(v.err, 0, RBPF_ERANGE);
-                ddx = 0; ddy = -1; x1 = x0; y1 = y0 - 1;                           // degenerate: no points
-            }
-            Ray r = ray_make(x0, y0, x1, y1);
-            int info = 0, nE = 0;
-            uint32_t fs = 0;
-            if (r.n > 0) {
-                info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
-                my_cells += (unsigned long long)r.n;
-                fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
-                fs = ev_fix_slope(r.dmin, r.dmaj);
-                const int a1 = lat_of(x1), b1 = lat_of(y1);
-                if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
-                    const int jn = r.n - 2, mn = ev_minor(fs, jn);
-                    const int nx = r.steep ? x0 + r.sx * mn : x0 + r.sx * jn, ny = r.steep ? y0 + r.sy * jn : y0 + r.sy * mn;
-                    if (lat_of(nx) == a1 && lat_of(ny) == b1) info |= RI_NEAR;        // hybridmap.py:141 same tile as the end cell
-                    info |= ((nx - x1 + 1) & 3) << 3;
-                    info |= ((ny - y1 + 1) & 3) << 5;
-                }
-                // tiles entered by this ray (staircase start -> [corner] -> end)
-                s_need[a0 * v.L + b0] = 1;
-                if (a1 != a0 || b1 != b0) {
-                    s_need[a1 * v.L + b1] = 1;
-                    if (a1 != a0 && b1 != b0) {
-                        int gxb_ = r.sx > 0 ? v.gwin[a1 * (KW + 1)] : v.gwin[a0 * (KW + 1)] - 1;
-                        int gyb_ = r.sy > 0 ? v.gwin[b1 * (KW + 1)] : v.gwin[b0 * (KW + 1)] - 1;
-                        int ox = gxb_ - x0; ox = ox < 0 ? -ox : ox;
-                        int oy = gyb_ - y0; oy = oy < 0 ? -oy : oy;
-                        int jx = r.steep ? first_j_minor_ge(r, ox) : ox;
-                        int jy = r.steep ? oy : first_j_minor_ge(r, oy);
-                        if (jx < jy) s_need[a1 * v.L + b0] = 1;
-                        else if (jy < jx) s_need[a0 * v.L + b1] = 1;
-                    }
-                }
-                // steps the walk takes: all of them but the beam's own occupied step and the pass before its own nearby hit
-                nE = r.n - ((info & RI_OCC) ? 1 : 0) - ((info & RI_NEAR) ? 1 : 0);
-                const int cls = (r.steep ? 4 : 0) | (ddx > 0 ? 2 : 0) | (ddy > 0 ? 1 : 0);
-                const int key = cls * NBIN + (int)(fs >> 24);
-                atomicAdd(reinterpret_cast<unsigned int*>(s_bins) + (key >> 1), 1u << ((key & 1) * 16));
-                if (nE > NEAR_R) atomicAdd(reinterpret_cast<unsigned int*>(s_far) + (key >> 1), 1u << ((key & 1) * 16));   // only these reach the 8-bit fields
-                const int nfull = (nE - NEAR_R) / LCH;                               // whole chunks beyond the 16-bit block
-                if (nE > NEAR_R && nfull >= 1) atomicAdd(&s_lcnt[min(nfull, MAXLEV)], 1);
-            }
-            o_fs[b] = fs;
-            o_end[b] = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
-            o_nE[b] = (uint16_t)nE;
-            o_info[b] = (uint8_t)info;
+    auto U_x = [&](int g) { return (int)ux[g - fxl]; };                       // unrolled storage coordinate
+    auto U_y = [&](int g) { return (int)uy[g - fyl]; };
+    const int a0 = UNI(U_x(x0)) / v.dim, b0 = UNI(U_y(y0)) / v.dim;           // biased lattice coordinate of the start cell
+    auto lat_x = [&](int g) { const int U = U_x(g); return a0 + (U >= (a0 + 1) * v.dim ? 1 : 0) - (U < a0 * v.dim ? 1 : 0); };   // (rays are shorter than a tile)
+    auto lat_y = [&](int g) { const int U = U_y(g); return b0 + (U >= (b0 + 1) * v.dim ? 1 : 0) - (U < b0 * v.dim ? 1 : 0); };
+    // the storage cells (U_x << 16 | U_y) flagged by a beam: its end cell and, when it lies in the end cell's tile, the cell before
+    auto beam_cells = [&](int info, int x1, int y1, uint32_t& sc0, uint32_t& sc1) {
+        sc0 = sc1 = 0xFFFFFFFFu;
+        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC)) return;
+        sc0 = ((uint32_t)U_x(x1) << 16) | (uint32_t)U_y(y1);
+        if (info & RI_NEAR) sc1 = ((uint32_t)U_x(x1 + ((info >> 3) & 3) - 1) << 16) | (uint32_t)U_y(y1 + ((info >> 5) & 3) - 1);
+    };
+    // per beam: end cell, ray, tiles, level, flagged cells; what later phases need of this thread's beams stays in registers
+    unsigned long long my_cells = 0;
+    int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
+    auto beam_setup = [&](int b, double x, double y, double bsc, int bf, int32_t& end_out, int& info_out, int& nE_out) {
+        double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
+        double gy = (s_s * x + s_c * y) + s_py;
+        int x1 = trunc_to_int(gx / v.cs), y1 = trunc_to_int(gy / v.cs);        // hybridmap.py:106
+        if (bf & BF_LONG) {                                                    // hybridmap.py:107-113
+            x1 = trunc_to_int((double)x0 + bsc * (double)(x1 - x0));
+            y1 = trunc_to_int((double)y0 + bsc * (double)(y1 - y0));
         }
+        int ddx = x1 - x0, ddy = y1 - y0;
+        if (ddx < -v.reach || ddx > v.reach || ddy < -v.reach || ddy > v.reach) {
+            atomicCAS(v.err, 0, RBPF_ERANGE);
+            ddx = 0; ddy = -1; x1 = x0; y1 = y0 - 1;                           // degenerate: no points
+        }
+        Ray r = ray_make(x0, y0, x1, y1);
+        int info = 0, nE = 0;
+        uint32_t fs = 0;
+        if (r.n > 0) {
+            info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
+            my_cells += (unsigned long long)r.n;
+            fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
+            fs = ev_fix_slope(r.dmin, r.dmaj);
+            const int a1 = lat_x(x1), b1 = lat_y(y1);
+            if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
+                const int jn = r.n - 2, mn = ev_minor(fs, jn);
+                const int nx = r.steep ? x0 + r.sx * mn : x0 + r.sx * jn, ny = r.steep ? y0 + r.sy * jn : y0 + r.sy * mn;
+                if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;          // hybridmap.py:141 same tile as the end cell
+                info |= ((nx - x1 + 1) & 3) << 3;
+                info |= ((ny - y1 + 1) & 3) << 5;
+            }
+            // tiles entered by this ray (staircase start -> [corner] -> end)
+            s_need[a0 * v.L + b0] = 1;
+            if (a1 != a0 || b1 != b0) {
+                s_need[a1 * v.L + b1] = 1;
+                if (a1 != a0 && b1 != b0) {
+                    int gxb_ = r.sx > 0 ? v.gwin[a1 * (KW + 1)] : v.gwin[a0 * (KW + 1)] - 1;
+                    int gyb_ = r.sy > 0 ? v.gwin[b1 * (KW + 1)] : v.gwin[b0 * (KW + 1)] - 1;
+                    int ox = gxb_ - x0; ox = ox < 0 ? -ox : ox;
+                    int oy = gyb_ - y0; oy = oy < 0 ? -oy : oy;
+                    int jx = r.steep ? first_j_minor_ge(r, ox) : ox;
+                    int jy = r.steep ? oy : first_j_minor_ge(r, oy);
+                    if (jx < jy) s_need[a1 * v.L + b0] = 1;
+                    else if (jy < jx) s_need[a0 * v.L + b1] = 1;
+                }
+            }
+            // steps the walk takes: all of them but the beam's own occupied step and the pass before its own nearby hit
+            nE = r.n - ((info & RI_OCC) ? 1 : 0) - ((info & RI_NEAR) ? 1 : 0);
+            const int cls = (r.steep ? 4 : 0) | (ddx > 0 ? 2 : 0) | (ddy > 0 ? 1 : 0);
+            const int key = cls * NBIN + (int)(fs >> 24);
+            atomicAdd(reinterpret_cast<unsigned int*>(s_bins) + (key >> 1), 1u << ((key & 1) * 16));
+            if (nE > NEAR_R) atomicAdd(reinterpret_cast<unsigned int*>(s_far) + (key >> 1), 1u << ((key & 1) * 16));   // only these reach the 8-bit fields
+            const int nfull = (nE - NEAR_R) / LCH;                               // whole chunks beyond the 16-bit block
+            if (nE > NEAR_R && nfull >= 1) atomicAdd(&s_lcnt[min(nfull, MAXLEV)], 1);
+            uint32_t sc0, sc1;                                                   // the beam's flagged cells: one more event each
+            beam_cells(info, x1, y1, sc0, sc1);
+            if (sc0 != 0xFFFFFFFFu) atomicAdd(&cnt[ev_hash_insert(keys, G.T, G.logT, sc0)], 1u);
+            if (sc1 != 0xFFFFFFFFu) atomicAdd(&cnt[ev_hash_insert(keys, G.T, G.logT, sc1)], 1u);
+        }
+        end_out = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
+        info_out = info; nE_out = nE;
+        o_fs[b] = fs; o_end[b] = end_out; o_nE[b] = (uint16_t)nE; o_info[b] = (uint8_t)info;
+    };
+    int32_t my_end[NPRE]; int my_info[NPRE], my_nE[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+        const int b = tid + i * PB;
+        my_end[i] = 0; my_info[i] = 0; my_nE[i] = 0;
+        if (b < v.B) beam_setup(b, pre_x[i], pre_y[i], pre_sc[i], pre_f[i], my_end[i], my_info[i], my_nE[i]);
+    }
+    for (int b = tid + NPRE * PB; b < v.B; b += PB) { int32_t e_; int i_, n_; beam_setup(b, v.bx[b], v.by[b], v.bscale[b], (int)v.bflags[b], e_, i_, n_); }
+    {
         const int ws = wave_sum((int)my_cells);
         fx0 = wave_min(fx0); fx1 = wave_max(fx1); fy0 = wave_min(fy0); fy1 = wave_max(fy1);
         if (lane == 0) {
@@ -270,13 +358,22 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
         }
     }
     __syncthreads();
+    PSTAMP(1);
     const int bxl = UNI(s_fan[0]), bxh = UNI(s_fan[1]), byl = UNI(s_fan[2]), byh = UNI(s_fan[3]);
     // the reference's index formula over the fan (one column more on either side): U(g) = g + C - G(g) with G in {0, 1}
-    for (int g = bxl - 1 + tid; g <= bxh + 1; g += PB) if ((unsigned)(g + C - U_of(g)) > 1u) s_fb = 1;
-    for (int g = byl - 1 + tid; g <= byh + 1; g += PB) if ((unsigned)(g + C - U_of(g)) > 1u) s_fb = 1;
+    {
+        uint8_t* const o_gxb = sp + SL.o_gxb;
+        uint8_t* const o_gyb = sp + SL.o_gyb;
+        for (int i = tid; i < G.fanw; i += PB) {
+            const int gx = fxl + i, gy = fyl + i;
+            const int dxg = ux[i] != 0xFFFFu ? gx + C - (int)ux[i] : 2, dyg = uy[i] != 0xFFFFu ? gy + C - (int)uy[i] : 2;
+            if (gx >= bxl - 1 && gx <= bxh + 1 && (unsigned)dxg > 1u) s_fb = 1;   // also: the LUT ends inside the fan
+            if (gy >= byl - 1 && gy <= byh + 1 && (unsigned)dyg > 1u) s_fb = 1;
+            o_gxb[i] = (uint8_t)(dxg & 1); o_gyb[i] = (uint8_t)(dyg & 1);
+        }
+    }
+    const int S_lo = U_x(bxl), S_hi = U_x(bxh), T_lo = U_y(byl), T_hi = U_y(byh);   // storage rows / columns the fan can write
     {   // the window must hold at least 8 rows of the fan's columns
-        const EvGeom G = ev_geom(v.B, v.reach);
-        const int T_lo = U_of(byl), T_hi = U_of(byh);
         const int gy_base = (T_lo - C) & ~3;
         int stride = (T_hi - C + 2 - gy_base + 3) & ~3;
         if (((stride >> 2) & 1) == 0) stride += 4;
@@ -309,8 +406,8 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
         if (k == 0) { hdr[H_NLEV] = nlev; hdr[H_NK] = 0; hdr[H_LP] = 0; }
     }
     {   // no 8-bit field can overflow: a cell at major distance j >= NEAR_R is hit, per direction class, only by rays
-        // whose slope lies in a window of width 2^32 / j + 1, i.e. in at most NB_WIN consecutive buckets.  First with all
-        // rays of the buckets, and only when that bound fails with the rays long enough to reach an 8-bit field.
+        // whose slope lies in a window of width 2^32 / j + 1, i.e. in at most NB_WIN consecutive buckets: bounded with all
+        // rays of those buckets, or (the smaller of the two) with the rays long enough to reach an 8-bit field.
         // inclusive prefix sums over the 2048 (class, bucket) counts, eight per thread
         int loc[8], loc2[8], run = 0, run2 = 0;
 #pragma unroll
@@ -324,24 +421,107 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s_bins[8 * tid + i] = (uint16_t)(base + loc[i]); s_far[8 * tid + i] = (uint16_t)(base2 + loc2[i]); }
         __syncthreads();
-        int mx = 0, mx2 = 0;
+        int mx2 = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int key = 8 * tid + i, cls = key / NBIN, bin = key % NBIN;
             const int hi = cls * NBIN + min(bin + NB_WIN - 1, NBIN - 1);
-            mx = max(mx, (int)s_bins[hi] - (key ? (int)s_bins[key - 1] : 0));
-            mx2 = max(mx2, (int)s_far[hi] - (key ? (int)s_far[key - 1] : 0));
+            mx2 = max(mx2, min((int)s_bins[hi] - (key ? (int)s_bins[key - 1] : 0), (int)s_far[hi] - (key ? (int)s_far[key - 1] : 0)));
         }
-        mx = wave_max(mx); mx2 = wave_max(mx2);
-        if (lane == 0 && mx > HIT_BOUND && mx2 > HIT_BOUND) s_exact = 1;
+        mx2 = wave_max(mx2);
+        if (lane == 0 && mx2 > HIT_BOUND) s_exact = 1;
+    }
+    __syncthreads();                                                          // (the buckets are done with: their place takes the events; the new tiles are in tab)
+    PSTAMP(2);
+    // ---- records of the flagged cells: index, first event slot (a cell with n events has n + 1 intervals), old value ----
+    {
+        const int per = G.T / PB;
+        int nrec = 0, nslot = 0;
+        for (int i = 0; i < per; ++i) { const int n = (int)cnt[tid * per + i]; nrec += n ? 1 : 0; nslot += n ? n + 1 : 0; }
+        int ir = nrec, is = nslot;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(ir, o, 64), t2 = __shfl_up(is, o, 64); if (lane >= o) { ir += t; is += t2; } }
+        if (lane == 63) { s_wsum[wave] = ir; s_wsum2[wave] = is; }
+        __syncthreads();
+        int r = ir - nrec, o = is - nslot, tot_r = 0, tot_s = 0;
+        for (int k = 0; k < PB / 64; ++k) { if (k < wave) { r += s_wsum[k]; o += s_wsum2[k]; } tot_r += s_wsum[k]; tot_s += s_wsum2[k]; }
+        if (tid == 0) { hdr[H_NR] = tot_r; hdr[H_NEV] = tot_s; }
+        uint32_t* const o_rkey = reinterpret_cast<uint32_t*>(sp + SL.o_rkey);
+        uint32_t* const o_rmeta = reinterpret_cast<uint32_t*>(sp + SL.o_rmeta);
+        int8_t* const o_roldv = reinterpret_cast<int8_t*>(sp + SL.o_roldv);
+        const int r_first = r;
+        for (int base = 0; base < per; base += 16) {                           // old values: sixteen loads in flight, then their stores
+            int8_t ov[16];
+            int rr = r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int h = tid * per + base + i, n = base + i < per ? (int)cnt[h] : 0;
+                ov[i] = 0;
+                if (base + i < per) o2[h] = (uint16_t)o;
+                if (!n) continue;
+                const uint32_t key = keys[h];
+                o_rkey[r] = key; o_rmeta[r] = (uint32_t)o | ((uint32_t)n << 16);
+                // rays are shorter than a tile, the lattice coordinate moves by at most one; a tile that was missing is new: zero
+                const int sx = (int)(key >> 16), sy = (int)(key & 0xFFFFu);
+                const int a = a0 + (sx >= (a0 + 1) * v.dim ? 1 : 0) - (sx < a0 * v.dim ? 1 : 0);
+                const int bb = b0 + (sy >= (b0 + 1) * v.dim ? 1 : 0) - (sy < b0 * v.dim ? 1 : 0);
+                const int tile = ((unsigned)a < (unsigned)v.L && (unsigned)bb < (unsigned)v.L) ? s_tab[a * v.L + bb] : -1;
+                if (tile >= 0) ov[i] = v.pool[(size_t)tile * v.dim * v.dim + (size_t)(sx - a * v.dim) * v.dim + (sy - bb * v.dim)];
+                ++r; o += n + 1;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = base + i < per ? (int)cnt[tid * per + base + i] : 0;
+                if (n) o_roldv[rr++] = ov[i];
+            }
+        }
+        (void)r_first;
     }
     __syncthreads();
+    PSTAMP(3);
+    // every beam puts its events (pair = beam << 1 | nearby) into its cells' slots ...
+    auto put_events = [&](int b, int32_t re, int info) {
+        uint32_t sc[2];
+        beam_cells(info, x0 + (int)(int16_t)(re & 0xFFFF), y0 + (int)(int16_t)((uint32_t)re >> 16), sc[0], sc[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (sc[e] == 0xFFFFFFFFu) continue;
+            const int h = ev_hash_find(keys, G.T, G.logT, sc[e]);
+            const int pos = (int)(atomicAdd(&cnt[h], 1u << 16) >> 16);
+            evl[(int)o2[h] + pos] = (uint16_t)(2 * b + e);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) { const int b = tid + i * PB; if (b < v.B) put_events(b, my_end[i], my_info[i]); }
+    for (int b = tid + NPRE * PB; b < v.B; b += PB) put_events(b, o_end[b], o_info[b]);          // (written by this thread)
+    __syncthreads();
+    PSTAMP(4);
+    // ... and finds its rank among them: sorted by counting (a handful per cell)
+    uint16_t* const o_evs = reinterpret_cast<uint16_t*>(sp + SL.o_evs);
+    auto rank_events = [&](int b, int32_t re, int info) {
+        uint32_t sc[2];
+        beam_cells(info, x0 + (int)(int16_t)(re & 0xFFFF), y0 + (int)(int16_t)((uint32_t)re >> 16), sc[0], sc[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (sc[e] == 0xFFFFFFFFu) continue;
+            const int h = ev_hash_find(keys, G.T, G.logT, sc[e]);
+            const int o = (int)o2[h], n = (int)(cnt[h] & 0xFFFFu), pr = 2 * b + e;
+            int rank = 0;
+            for (int i = 0; i < n; ++i) rank += (int)evl[o + i] < pr;
+            o_evs[o + rank] = (uint16_t)pr;
+        }
+    };
     // rays ordered by falling count of whole chunks
-    for (int b = tid; b < v.B; b += PB) {
-        const int nE = o_nE[b];                                                   // (written by this thread)
+    auto put_perm = [&](int b, int nE) {
         const int nfull = (nE - NEAR_R) / LCH;
         if (nE > NEAR_R && nfull >= 1) o_perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) { const int b = tid + i * PB; if (b < v.B) { rank_events(b, my_end[i], my_info[i]); put_perm(b, my_nE[i]); } }
+    for (int b = tid + NPRE * PB; b < v.B; b += PB) { rank_events(b, o_end[b], o_info[b]); put_perm(b, (int)o_nE[b]); }
+    PSTAMP(5);
+#if defined(RBPF_STAMPS) && defined(STAMP_PRE)
+    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
+#endif
     if (tid == 0) {
         const int fb = s_fb ? 1 : s_exact ? 2 : 0;
         if (fb) {
@@ -349,6 +529,7 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
             atomicAdd(&v.stats[fb == 1 ? ST_FALLBACK_REASONS : ST_FB_BOUND], 1ull);
         } else {
             hdr[H_X0] = x0; hdr[H_Y0] = y0; hdr[H_BXL] = bxl; hdr[H_BXH] = bxh; hdr[H_BYL] = byl; hdr[H_BYH] = byh;
+            hdr[H_SLO] = S_lo; hdr[H_SHI] = S_hi; hdr[H_TLO] = T_lo; hdr[H_THI] = T_hi; hdr[H_A0] = a0; hdr[H_B0] = b0;
             hdr[H_CELLS] = (int)s_cells;
             hdr[H_STATUS] = 1;
         }
@@ -359,11 +540,9 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
 __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const EvScratch SL = ev_scratch(v.ev_maxb);
+    const EvScratch SL = ev_scratch(v.ev_maxb, v.reach);
     const unsigned char* const sp = v.ev_scratch + (size_t)p * SL.stride;
     const int32_t* const hdr = reinterpret_cast<const int32_t*>(sp);
-    if (UNI(hdr[H_STATUS]) != 1) return;
-
     const EvGeom G = ev_geom(v.B, v.reach);
     uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.o_cnt);     // 8-bit fields: bit 0 = flagged, bits 1-7 = passes; [row = global x][col = global y]
     uint8_t*  const cnt8 = smem + G.o_cnt;
@@ -373,63 +552,58 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     uint16_t* const r_nE = reinterpret_cast<uint16_t*>(smem + G.o_nE);     // [B] steps the walk takes
     uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole chunks
     uint8_t*  const r_info = smem + G.o_info;                              // [B]
-    uint8_t*  const oldv8 = smem + G.o_oldv;                               // [2 B] value of the pair's cell before the scan
-    uint16_t* const ux = reinterpret_cast<uint16_t*>(smem + G.o_ux);       // U of global column fxl + i
-    uint16_t* const uy = reinterpret_cast<uint16_t*>(smem + G.o_uy);
     uint8_t*  const gxb = smem + G.o_gxb;                                  // G of global column fxl + i (0 / 1)
     uint8_t*  const gyb = smem + G.o_gyb;
     uint8_t*  const gym = smem + G.o_gym;                                  // G of window column lc as a byte mask (0 / 0xFF)
     uint32_t* const evlist = reinterpret_cast<uint32_t*>(smem + G.o_evl);  // [EVCAP] beam << 10 | step: passes over flagged cells
 
     __shared__ int s_tab[49];
-    __shared__ int s_nk[MAXLEV + 2], s_lp[MAXLEV + 3];
-    __shared__ int s_wsum[EB / 64];
+    __shared__ int s_hdr[H_LP + MAXLEV + 3];
+    int* const s_nk = s_hdr + H_NK;                   // [MAXLEV + 1] rays with at least k whole chunks
+    int* const s_lp = s_hdr + H_LP;                   // [MAXLEV + 2] first wave-item of level k
     __shared__ int s_nev, s_written;
     __shared__ uint8_t s_ggf[192];                    // per (tile column, 32-column group): a glitched column among its 33
 
     const int LL = v.L * v.L;
     const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
-#ifdef RBPF_STAMPS
+#if defined(RBPF_STAMPS) && !defined(STAMP_PRE)
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
 #endif
-    // =============================================== staging ===============================================
-    const int x0 = UNI(hdr[H_X0]), y0 = UNI(hdr[H_Y0]);
-    const int bxl = UNI(hdr[H_BXL]), bxh = UNI(hdr[H_BXH]), byl = UNI(hdr[H_BYL]), byh = UNI(hdr[H_BYH]);
-    const int nlev = UNI(hdr[H_NLEV]);
+    // ====================== staging (one round trip: no address below depends on a loaded value) ======================
     {
         const uint32_t* g_fs = reinterpret_cast<const uint32_t*>(sp + SL.o_fs);
         const int32_t* g_end = reinterpret_cast<const int32_t*>(sp + SL.o_end);
         const uint16_t* g_nE = reinterpret_cast<const uint16_t*>(sp + SL.o_nE);
         const uint16_t* g_perm = reinterpret_cast<const uint16_t*>(sp + SL.o_perm);
         const uint8_t* g_info = sp + SL.o_info;
-        const int nperm = UNI(hdr[H_NK + 1]);                                  // rays with at least one whole chunk
-        for (int b = tid; b < v.B; b += EB) {
-            r_fs[b] = g_fs[b]; r_end[b] = g_end[b]; r_nE[b] = g_nE[b]; r_info[b] = g_info[b];
-            if (b < nperm) perm[b] = g_perm[b];
-        }
+        for (int b = tid; b < v.B; b += EB) { r_fs[b] = g_fs[b]; r_end[b] = g_end[b]; r_nE[b] = g_nE[b]; r_info[b] = g_info[b]; perm[b] = g_perm[b]; }
+        const uint32_t* g_gxb = reinterpret_cast<const uint32_t*>(sp + SL.o_gxb);
+        const uint32_t* g_gyb = reinterpret_cast<const uint32_t*>(sp + SL.o_gyb);
+        for (int i = tid; i < G.fanw / 4; i += EB) { reinterpret_cast<uint32_t*>(gxb)[i] = g_gxb[i]; reinterpret_cast<uint32_t*>(gyb)[i] = g_gyb[i]; }
+        for (int i = tid; i < LL; i += EB) s_tab[i] = tab[i];
+        if (tid < H_LP + MAXLEV + 2) s_hdr[tid] = hdr[tid];
+        if (tid == 0) { s_nev = 0; s_written = 0; }
+        if (tid < 192) s_ggf[tid] = 0;
+        for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += EB) mini[i] = 0;
     }
-    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2, nfx = 2 * v.reach + 5;
-    const int C = v.R * v.dim + v.dim / 2;
-    for (int i = tid; i < G.fanw; i += EB) {
-        const int gxq = fxl + i, gyq = fyl + i;
-        const uint32_t ex = lut_valid_g(v, gxq) ? lut_at(v, gxq) : LUT_INVALID, ey = lut_valid_g(v, gyq) ? lut_at(v, gyq) : LUT_INVALID;
-        const int Ux = ex != LUT_INVALID ? lut_lat(ex) * v.dim + lut_cidx(ex) : 0xFFFF, Uy = ey != LUT_INVALID ? lut_lat(ey) * v.dim + lut_cidx(ey) : 0xFFFF;
-        ux[i] = (uint16_t)Ux; uy[i] = (uint16_t)Uy;
-        gxb[i] = (uint8_t)((gxq + C - Ux) & 1); gyb[i] = (uint8_t)((gyq + C - Uy) & 1);
-    }
-    for (int i = tid; i < LL; i += EB) s_tab[i] = tab[i];
-    if (tid <= MAXLEV + 1) s_nk[tid] = tid <= MAXLEV ? hdr[H_NK + tid] : 0;
-    if (tid <= MAXLEV + 1) s_lp[tid] = tid <= MAXLEV + 1 ? hdr[H_LP + tid] : 0;
-    if (tid == 0) { s_nev = 0; s_written = 0; }
-    if (tid < 192) s_ggf[tid] = 0;
-    for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += EB) mini[i] = 0;
+    const uint32_t* const g_rkey = reinterpret_cast<const uint32_t*>(sp + SL.o_rkey);
+    const uint32_t* const g_rmeta = reinterpret_cast<const uint32_t*>(sp + SL.o_rmeta);
+    const int8_t* const g_roldv = reinterpret_cast<const int8_t*>(sp + SL.o_roldv);
+    const uint16_t* const g_evs = reinterpret_cast<const uint16_t*>(sp + SL.o_evs);
+    // this thread's records (two per thread cover 2048; more: the loops below read the rest from memory); loaded whatever
+    // the record count turns out to be
+    const int rcap = 2 * SL.bpad - 1;
+    const uint32_t my_key0 = g_rkey[min(tid, rcap)], my_key1 = g_rkey[min(tid + EB, rcap)];
     __syncthreads();
+    if (UNI(s_hdr[H_STATUS]) != 1) return;
+    const int x0 = UNI(s_hdr[H_X0]), y0 = UNI(s_hdr[H_Y0]);
+    const int nlev = UNI(s_hdr[H_NLEV]), NR = UNI(s_hdr[H_NR]), NEV = UNI(s_hdr[H_NEV]);
+    const int S_lo = UNI(s_hdr[H_SLO]), S_hi = UNI(s_hdr[H_SHI]), T_lo = UNI(s_hdr[H_TLO]), T_hi = UNI(s_hdr[H_THI]);   // storage rows / columns the fan can write
+    const int a0 = UNI(s_hdr[H_A0]), b0 = UNI(s_hdr[H_B0]);
     STAMP(0);
 
-    const int Uxs = UNI(ux[x0 - fxl]), Uys = UNI(uy[y0 - fyl]);
-    const int a0 = Uxs / v.dim, b0 = Uys / v.dim;
-    const int S_lo = UNI(ux[bxl - fxl]), S_hi = UNI(ux[bxh - fxl]);           // storage rows / columns the fan can write
-    const int T_lo = UNI(uy[byl - fyl]), T_hi = UNI(uy[byh - fyl]);
+    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2, nfx = 2 * v.reach + 5;
+    const int C = v.R * v.dim + v.dim / 2;
     const int gy_base = (T_lo - C) & ~3;                                      // window column 0 (C is a multiple of 4)
     int stride = (T_hi - C + 2 - gy_base + 3) & ~3;                           // columns gy_base .. T_hi - C + 1
     if (((stride >> 2) & 1) == 0) stride += 4;                                // rows an odd number of banks apart
@@ -448,16 +622,6 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         }
     }
 
-    // the storage cell (U_x << 16 | U_y) flagged by pair (beam, e): the beam's end cell (e = 0) or the cell before it (e = 1,
-    // only when it lies in the end cell's tile); ~0 = none
-    auto pair_cell = [&](int pr) -> uint32_t {
-        const int b = pr >> 1, info = r_info[b];
-        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC) || ((pr & 1) && !(info & RI_NEAR))) return 0xFFFFFFFFu;
-        const int32_t re = r_end[b];
-        int x1 = x0 + (int)(int16_t)(re & 0xFFFF), y1 = y0 + (int)(int16_t)((uint32_t)re >> 16);
-        if (pr & 1) { x1 += ((info >> 3) & 3) - 1; y1 += ((info >> 5) & 3) - 1; }
-        return ((uint32_t)ux[x1 - fxl] << 16) | (uint32_t)uy[y1 - fyl];
-    };
     struct FCell { int sx, sy; int gx0, gx1, gy0, gy1; int ngx, ngy; };            // storage cell and its source global cells
     auto cell_sources = [&](uint32_t sc, FCell& f) {
         f.sx = (int)(sc >> 16); f.sy = (int)(sc & 0xFFFFu);
@@ -485,12 +649,12 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);        // passes that saturate any cell: 20
     const uint32_t satb = (uint32_t)sat * 0x01010101u, sadd = (128u - (uint32_t)sat) * 0x01010101u;
     const int cnt_lds = ev_lds_addr(cnt), mini_lds = ev_lds_addr(mini);
-    // a lane's steps that met a flagged cell (bit 15 - u of m = step j0 + u): into the event list
+    // a lane's steps that met a flagged cell (bit 16 + u of m = step j0 + u): into the event list
     auto log_events = [&](uint32_t m, int b, int j0, int ev_lo, int ev_hi, int gx_base, bool filter) {
         while (m) {
-            const int hb = 31 - __clz((int)m);
-            m ^= 1u << hb;
-            const int j = j0 + 15 - hb;
+            const int lb = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int j = j0 + lb - 16;
             if (filter) {   // strips share a global row with their neighbours: the strip that owns its storage row reports
                 const RayDir d = ray_dir(b);
                 const int row = x0 + d.sx * (d.steep ? ev_minor(r_fs[b], j) : j) - gx_base;
@@ -500,7 +664,6 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             if (pos < EVCAP) evlist[pos] = ((uint32_t)b << 10) | (uint32_t)j;
         }
     };
-    BAR_LDS();
 
     // =============================================== windows ==============================================
     int n_win = 0;
@@ -517,16 +680,10 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         BAR_LDS();
         // ---- flags: every global cell that maps to a storage cell with an occupied / nearby hit; the flag comes with a
         //      count of one, so a flagged field is never zero (the write-back takes "touched" from the field) ----
-        for (int pr = tid; pr < 2 * v.B; pr += EB) {
-            const uint32_t sc = pair_cell(pr);
-            if (sc == 0xFFFFFFFFu) continue;
+        for (int r = tid; r < NR; r += EB) {
+            const uint32_t sc = r == tid ? my_key0 : r == tid + EB ? my_key1 : g_rkey[r];
             FCell f;
             cell_sources(sc, f);
-            if (n_win == 0) {
-                int tile, row_t, col_t;
-                cell_addr(f.sx, f.sy, tile, row_t, col_t);
-                oldv8[pr] = (uint8_t)(tile >= 0 ? (int)v.pool[(size_t)tile * v.dim * v.dim + (size_t)row_t * v.dim + col_t] : 0);
-            }
 #pragma unroll
             for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
@@ -560,16 +717,18 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                 const int d0 = mj, d1 = mj + mm;
                 uint32_t acc = 0x80000000u, m = 0;
                 int c = NEAR_R * NEAR_W + NEAR_R + (mini_lds >> 1);                    // field index, the array's LDS address folded in
+                uint32_t ret[NEAR_R]; int sh[NEAR_R];
 #pragma unroll
                 for (int u = 0; u < NEAR_R; ++u) {
-                    const bool in = u < nE;
-                    const uint32_t ret = ev_lds_add_rtn((c << 1) & ~3, (in ? 2u : 0u) << ((c << 4) & 31));
-                    const uint32_t f = in ? __builtin_amdgcn_ubfe(ret, (c << 4) & 31, 1) : 0u;
-                    m = (m << 1) | f;
+                    sh[u] = c << 4;
+                    ret[u] = ev_lds_add_rtn((c << 1) & ~3, (u < nE ? 2u : 0u) << (sh[u] & 31));
                     const uint32_t nacc = acc + fs;
                     c += nacc < acc ? d1 : d0;
                     acc = nacc;
                 }
+                __builtin_amdgcn_sched_barrier(0);                                     // sixteen adds in flight, then their answers
+#pragma unroll
+                for (int u = 0; u < NEAR_R; ++u) m = __builtin_amdgcn_alignbit(u < nE ? ret[u] >> (sh[u] & 31) : 0u, m, 1);
                 if (m) log_events(m, b, 0, 0, 0, 0, false);
             }
         }
@@ -582,41 +741,61 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             const int base0 = rx0 * stride + ry0 + cnt_lds;
             const int win_lo = cnt_lds, win_n = rows_w * stride;
             const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
-            for (int q = wave; q < nitems; q += EB / 64) {
-                int k = 1;
-                for (int kk = 2; kk <= nlev; ++kk) if (q >= UNI(s_lp[kk])) k = kk;
-                const int nk = UNI(s_nk[k]), nwk = (nk + 63) >> 6, wslot = q - UNI(s_lp[k]);
+            // the next item's ray is fetched while this one's adds are in flight
+            int k = 1, kn = 1;
+            int nb = -1; uint32_t nfs = 0; int32_t nend = 0;
+            auto fetch_item = [&](int q) {
+                nb = -1;
+                if (q >= nitems) return;
+                while (kn < nlev && q >= UNI(s_lp[kn + 1])) ++kn;
+                const int nk = UNI(s_nk[kn]), nwk = (nk + 63) >> 6, wslot = q - UNI(s_lp[kn]);
                 const int ii = lane * nwk + wslot;
-                if (ii >= nk) continue;
-                const int b = perm[ii];
-                const uint32_t fs = r_fs[b];
-                const RayDir d = ray_dir(b);
-                const int sxs = d.sx * stride;
-                const int cj = d.steep ? d.sy : sxs, cm = d.steep ? sxs : d.sy;
+                if (ii < nk) { nb = perm[ii]; nfs = r_fs[nb]; nend = r_end[nb]; }
+            };
+            fetch_item(wave);
+            for (int q = wave; q < nitems; q += EB / 64) {
+                const int b = nb; const uint32_t fs = nfs; const int32_t re = nend;
+                k = kn;
+                if (b < 0) { fetch_item(q + EB / 64); continue; }
+                const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
+                const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+                const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
+                const int cj = aey > aex ? sy1 : sxs, cm = aey > aex ? sxs : sy1;
                 const int j0 = NEAR_R + (k - 1) * LCH;
                 const unsigned long long pr64 = (unsigned long long)fs * (unsigned)j0 + 0x80000000ull;
                 uint32_t acc = (uint32_t)pr64, m = 0;
                 int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
                 const int d0 = cj, d1 = cj + cm;
+                uint32_t ret[LCH]; int sh[LCH];
                 if (whole) {
 #pragma unroll
                     for (int u = 0; u < LCH; ++u) {
-                        const uint32_t ret = ev_lds_add_rtn(c & ~3, 2u << ((c << 3) & 31));
-                        m = (m << 1) | __builtin_amdgcn_ubfe(ret, (c << 3) & 31, 1);
+                        sh[u] = c << 3;
+                        ret[u] = ev_lds_add_rtn(c & ~3, 2u << (sh[u] & 31));
                         const uint32_t nacc = acc + fs;
                         c += nacc < acc ? d1 : d0;
                         acc = nacc;
                     }
+                    fetch_item(q + EB / 64);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit(ret[u] >> (sh[u] & 31), m, 1);
                 } else {
+                    uint32_t inm = 0;
 #pragma unroll
                     for (int u = 0; u < LCH; ++u) {
                         const bool in = (unsigned)(c - win_lo) < (unsigned)win_n;       // the columns always fit: a test of the row
-                        const uint32_t ret = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << ((c << 3) & 31));
-                        m = (m << 1) | (in ? __builtin_amdgcn_ubfe(ret, (c << 3) & 31, 1) : 0u);
+                        sh[u] = c << 3;
+                        ret[u] = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << (sh[u] & 31));
+                        inm |= in ? 1u << u : 0u;
                         const uint32_t nacc = acc + fs;
                         c += nacc < acc ? d1 : d0;
                         acc = nacc;
                     }
+                    fetch_item(q + EB / 64);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit((inm >> u) & (ret[u] >> (sh[u] & 31)), m, 1);
                 }
                 if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
             }
@@ -632,19 +811,24 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                 const int sxs = d.sx * stride;
                 const int cj = d.steep ? d.sy : sxs, cm = d.steep ? sxs : d.sy;
                 const unsigned long long pr64 = (unsigned long long)fs * (unsigned)j0 + 0x80000000ull;
-                uint32_t acc = (uint32_t)pr64, m = 0;
+                uint32_t acc = (uint32_t)pr64, m = 0, inm = 0;
                 int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
                 const int d0 = cj, d1 = cj + cm;
+                uint32_t ret[LCH - 1]; int sh[LCH - 1];
 #pragma unroll
                 for (int u = 0; u < LCH - 1; ++u) {                                // branch-free: a dead step adds nothing to a word of the lane's own
                     const bool in = u < left && (whole || (unsigned)(c - win_lo) < (unsigned)win_n);
-                    const uint32_t ret = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << ((c << 3) & 31));
-                    m = (m << 1) | (in ? __builtin_amdgcn_ubfe(ret, (c << 3) & 31, 1) : 0u);
+                    sh[u] = c << 3;
+                    ret[u] = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << (sh[u] & 31));
+                    inm |= in ? 1u << u : 0u;
                     const uint32_t nacc = acc + fs;
                     c += nacc < acc ? d1 : d0;
                     acc = nacc;
                 }
-                m <<= 1;                                                          // (15 steps: bit 15 - u as in a whole chunk)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < LCH - 1; ++u) m = __builtin_amdgcn_alignbit((inm >> u) & (ret[u] >> (sh[u] & 31)), m, 1);
+                m >>= 1;                                                          // (15 steps: bit 16 + u as in a whole chunk)
                 if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
             }
         }
@@ -762,7 +946,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                     } else {
 #pragma unroll
                         for (int w = 0; w < 8; ++w) if (w < nw) g_ptr[w] = out[w];
-                        occ &= (nw == 8) ? 0xFFFFFFFFu : ((1u << (4 * nw)) - 1u);           // (cells past the tile's last column are not cells)
+                        occ &= (1u << (4 * nw)) - 1u;                                      // (cells past the tile's last column are not cells)
                     }
                     my_written += __popc(touched);
                     by0 = min(by0, col_t + __ffs(touched) - 1); by1 = max(by1, col_t + 31 - __clz(touched));
@@ -780,77 +964,28 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         }
         STAMP(4);
     }
-    __syncthreads();                                                          // every store of the write-back has landed: the flagged cells' bytes follow
+    // this thread's records again: their event slots, their old values; the sorted events (all in flight across the barriers)
+    const uint32_t my_meta0 = tid < NR ? g_rmeta[tid] : 0u, my_meta1 = tid + EB < NR ? g_rmeta[tid + EB] : 0u;
+    const int my_old0 = tid < NR ? (int)g_roldv[tid] : 0, my_old1 = tid + EB < NR ? (int)g_roldv[tid + EB] : 0;
+    const int nevw = (NEV + 1) / 2;
+    const uint32_t my_ev0 = tid < nevw ? reinterpret_cast<const uint32_t*>(g_evs)[tid] : 0u, my_ev1 = tid + EB < nevw ? reinterpret_cast<const uint32_t*>(g_evs)[tid + EB] : 0u;
+    BAR_LDS();                                                                // the window's LDS is free (the write-back's stores are still on their way)
 
-    // ======================================== flagged cells (the window's LDS is free) ========================================
+    // ======================================== flagged cells ========================================
     uint32_t* const keys = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_keys);    // [T] storage cell, ~0 = empty
-    uint32_t* const cnta = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_cnta);    // [T] occupied / nearby events of the cell
-    uint32_t* const offs = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_offs);    // [T] first event | events << 16
-    uint16_t* const rep = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_rep);      // [T] one of the cell's pairs
-    uint16_t* const evl = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_evl);      // [E] events (pair = beam << 1 | nearby) as they arrive
-    uint16_t* const evs = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_evs);      // [E] sorted
+    uint16_t* const rec = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_rec);      // [T] record of the slot's cell
+    uint16_t* const evs = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_evs);      // [E] events (pair = beam << 1 | nearby), sorted per record
     uint32_t* const ic32 = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_ic);      // [E] 16-bit pass counts of the intervals
     const uint16_t* const ic16 = reinterpret_cast<const uint16_t*>(ic32);
-    uint16_t* const pslot = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_pslot);  // [2 B] table slot of the pair's cell
     const int T = G.T;
     const int nev_all = UNI(s_nev);
     const bool overflow = nev_all > EVCAP;
-    for (int i = tid; i < T; i += EB) { keys[i] = 0xFFFFFFFFu; cnta[i] = 0; }
+    for (int i = tid; i < T; i += EB) keys[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < nevw; i += EB) { ic32[i] = 0; reinterpret_cast<uint32_t*>(evs)[i] = i == tid ? my_ev0 : i == tid + EB ? my_ev1 : reinterpret_cast<const uint32_t*>(g_evs)[i]; }
     BAR_LDS();
-    auto slot_of = [&](uint32_t sc) {                                          // find (the cell is in the table)
-        uint32_t h = (sc * 2654435761u) >> (32 - G.logT);
-        for (int it = 0; it < T; ++it) { const uint32_t k = keys[h]; if (k == sc) return (int)h; if (k == 0xFFFFFFFFu) return -1; h = (h + 1) & (uint32_t)(T - 1); }
-        return -1;
-    };
-    for (int pr = tid; pr < 2 * v.B; pr += EB) {
-        const uint32_t sc = pair_cell(pr);
-        if (sc == 0xFFFFFFFFu) continue;
-        uint32_t h = (sc * 2654435761u) >> (32 - G.logT);
-        for (;;) {
-            const uint32_t old = atomicCAS(&keys[h], 0xFFFFFFFFu, sc);
-            if (old == 0xFFFFFFFFu || old == sc) break;
-            h = (h + 1) & (uint32_t)(T - 1);                                     // (at most 2 B cells in a table of 3 B slots or more)
-        }
-        pslot[pr] = (uint16_t)h;
-        atomicAdd(&cnta[h], 1u);
-        rep[h] = (uint16_t)pr;
-    }
-    BAR_LDS();
-    {   // a cell with n events gets n event slots and n + 1 intervals at the same offset: exclusive prefix of (n + 1)
-        const int per = T / EB;
-        int loc = 0;
-        for (int i = 0; i < per; ++i) { const int n = (int)cnta[tid * per + i]; loc += n ? n + 1 : 0; }
-        int incl = loc;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) s_wsum[wave] = incl;
-        BAR_LDS();
-        int run = incl - loc;
-        for (int k = 0; k < wave; ++k) run += s_wsum[k];
-        for (int i = 0; i < per; ++i) {
-            const int n = (int)cnta[tid * per + i];
-            offs[tid * per + i] = (uint32_t)run | ((uint32_t)n << 16);
-            run += n ? n + 1 : 0;
-        }
-    }
-    BAR_LDS();
-    for (int pr = tid; pr < 2 * v.B; pr += EB) {
-        if (pair_cell(pr) == 0xFFFFFFFFu) continue;
-        const int h = pslot[pr];
-        const uint32_t of = offs[h];
-        const int o2 = (int)(of & 0xFFFFu), n = (int)(of >> 16);
-        const int pos = (int)atomicSub(&cnta[h], 1u) - 1;
-        evl[o2 + pos] = (uint16_t)pr;
-        reinterpret_cast<uint16_t*>(ic32)[o2 + pos] = 0;
-        if (pos == 0) reinterpret_cast<uint16_t*>(ic32)[o2 + n] = 0;
-    }
-    BAR_LDS();
-    for (int pr = tid; pr < 2 * v.B; pr += EB) {                                // sort by counting: a handful of events per cell
-        if (pair_cell(pr) == 0xFFFFFFFFu) continue;
-        const uint32_t of = offs[pslot[pr]];
-        const int o2 = (int)(of & 0xFFFFu), n = (int)(of >> 16);
-        int rank = 0;
-        for (int i = 0; i < n; ++i) rank += (int)evl[o2 + i] < pr;
-        evs[o2 + rank] = (uint16_t)pr;
+    for (int r = tid; r < NR; r += EB) {
+        const uint32_t sc = r == tid ? my_key0 : r == tid + EB ? my_key1 : g_rkey[r];
+        rec[ev_hash_insert(keys, T, G.logT, sc)] = (uint16_t)r;
     }
     BAR_LDS();
     STAMP(5);
@@ -863,9 +998,10 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             const RayDir d = ray_dir(b);
             const int mn = ev_minor(r_fs[b], j);
             const int gx = x0 + d.sx * (d.steep ? mn : j), gy = y0 + d.sy * (d.steep ? j : mn);
-            const int h = slot_of(((uint32_t)ux[gx - fxl] << 16) | (uint32_t)uy[gy - fyl]);
+            const int Ux = gx + C - (int)gxb[gx - fxl], Uy = gy + C - (int)gyb[gy - fyl];
+            const int h = ev_hash_find(keys, T, G.logT, ((uint32_t)Ux << 16) | (uint32_t)Uy);
             if (h < 0) continue;                                                 // (cannot happen: only flagged fields report)
-            const uint32_t of = offs[h];
+            const uint32_t of = g_rmeta[rec[h]];
             const int o2 = (int)(of & 0xFFFFu), n = (int)(of >> 16);
             int lo = 0, hi = n;                                                  // first event of a beam >= b
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (((int)evs[o2 + mid] >> 1) < b) lo = mid + 1; else hi = mid; }
@@ -873,7 +1009,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             atomicAdd(&ic32[at >> 1], 1u << ((at & 1) * 16));
         }
     }
-    BAR_LDS();
+    __syncthreads();                                                          // every store of the write-back has landed: the flagged cells' bytes follow
     STAMP(6);
     // the byte and the occupancy bit of a flagged cell
     auto store_cell = [&](uint32_t key, int val) {
@@ -885,49 +1021,45 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         if (val > v.cc.thr) atomicOr(ow, 1u << (col_t & 31)); else atomicAnd(ow, ~(1u << (col_t & 31)));
     };
     if (!overflow) {
-        for (int h = tid; h < T; h += EB) {
-            const uint32_t of = offs[h];
+        for (int r = tid; r < NR; r += EB) {
+            const uint32_t key = r == tid ? my_key0 : r == tid + EB ? my_key1 : g_rkey[r];
+            const uint32_t of = r == tid ? my_meta0 : r == tid + EB ? my_meta1 : g_rmeta[r];
+            int val = r == tid ? my_old0 : r == tid + EB ? my_old1 : (int)g_roldv[r];
             const int o2 = (int)(of & 0xFFFFu), n = (int)(of >> 16);
-            if (n == 0) continue;
-            int val = (int)(int8_t)oldv8[rep[h]];
             int prev_beam = -1;
             for (int i = 0; i < n; ++i) {
-                const int key = evs[o2 + i], beam = key >> 1;
+                const int ek = evs[o2 + i], beam = ek >> 1;
                 // the beam's own pass over the cell before its nearby hit is not in the list: it precedes the beam's first event here
-                const bool has_near = (key & 1) || (i + 1 < n && (int)evs[o2 + i + 1] == key + 1);
+                const bool has_near = (ek & 1) || (i + 1 < n && (int)evs[o2 + i + 1] == ek + 1);
                 const int np = (int)ic16[o2 + i] + ((beam != prev_beam && has_near) ? 1 : 0);
                 val = max(val + min(np, sat) * v.cc.emp, v.cc.vmin);              // gridmap.py:97-101, np times
-                val = min(val + ((key & 1) ? v.cc.nearby : v.cc.occ), v.cc.vmax); // gridmap.py:86-90 / 108-112
+                val = min(val + ((ek & 1) ? v.cc.nearby : v.cc.occ), v.cc.vmax);  // gridmap.py:86-90 / 108-112
                 prev_beam = beam;
             }
             val = max(val + min((int)ic16[o2 + n], sat) * v.cc.emp, v.cc.vmin);
-            store_cell(keys[h], val);
+            store_cell(key, val);
         }
     } else {
         // more passes over flagged cells than the list holds: every flagged cell is replayed by a wave with the exact
         // closed-form membership test over all beams (rbpf_mapupdate.h), whatever the list says
-        int nslow = 0;
-        for (int h = wave; h < T; h += EB / 64) {
-            const uint32_t of = offs[h];
-            if ((of >> 16) == 0) continue;
-            const uint32_t key = keys[h];
+        for (int r = wave; r < NR; r += EB / 64) {
+            const uint32_t key = g_rkey[r];
             FCell f;
             cell_sources(key, f);
             const int gxc[2] = {f.gx0, f.gx1}, gyc[2] = {f.gy0, f.gy1};
-            const int val = replay_cell_wave(v, r_info, r_end, x0, y0, gxc, f.ngx, gyc, f.ngy, (int)(int8_t)oldv8[rep[h]], lane);
+            const int val = replay_cell_wave(v, r_info, r_end, x0, y0, gxc, f.ngx, gyc, f.ngy, (int)g_roldv[r], lane);
             if (lane == 0) store_cell(key, val);
-            ++nslow;
         }
-        if (lane == 0 && nslow) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)nslow);
+        if (tid == 0) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)NR);
     }
     STAMP(7);
     if (tid == 0) {
-        atomicAdd(&v.stats[ST_RAY_CELLS], (unsigned long long)hdr[H_CELLS]);
+        atomicAdd(&v.stats[ST_RAY_CELLS], (unsigned long long)s_hdr[H_CELLS]);
         if (s_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_written);
         atomicAdd(&v.stats[ST_MAP_WINDOWS], (unsigned long long)n_win);
         atomicAdd(&v.stats[ST_MAP_EVENTS], (unsigned long long)nev_all);
         if (overflow) atomicAdd(&v.stats[ST_EV_OVERFLOWS], 1ull);
-#ifdef RBPF_STAMPS
+#if defined(RBPF_STAMPS) && !defined(STAMP_PRE)
         for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
 #endif
     }
@@ -935,9 +1067,10 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
 
 void launch_map_update_ev(const DevView& v, hipStream_t s) {
     const EvGeom g = ev_geom(v.B, v.reach);
-    static size_t lds_set[MAX_DEVICES] = {};
+    static size_t lds_set[MAX_DEVICES] = {}, lds_set_pre[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_ev_kernel), (size_t)g.bytes, lds_set);
-    hipLaunchKernelGGL(map_rays_kernel, dim3(v.P), dim3(PB), 0, s, v);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(map_rays_kernel), (size_t)g.pre_bytes, lds_set_pre);
+    hipLaunchKernelGGL(map_rays_kernel, dim3(v.P), dim3(PB), (size_t)g.pre_bytes, s, v);
     hipLaunchKernelGGL(map_update_ev_kernel, dim3(v.P), dim3(EB), (size_t)g.bytes, s, v);
 }
 

@@ -162,7 +162,7 @@ void launch_map_update_fan(const DevView& v, hipStream_t s);
 bool map_update_ray_available(const DevView& v);
 void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s);
 bool map_update_ev_available(const DevView& v);
-size_t map_update_ev_scratch_bytes(int max_beams);
+size_t map_update_ev_scratch_bytes(int max_beams, int reach);
 void launch_map_update_ev(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);

@@ -1,7 +1,7 @@
 """Developer probe: map update only, whole-fan kernel vs the 128x128-window kernel (timing + fallback counters)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from thesis_amd import engine
 from thesis_amd.datasets import synthetic
 

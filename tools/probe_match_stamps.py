@@ -1,8 +1,8 @@
 """Diagnostic: per-phase cycle shares of the scan-match kernel (needs a -DRBPF_STAMPS build with the map-update
 stamps disabled, see RBPF_STAMPS=match)."""
-import sys
+import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import Runner, PERIOD_S
 from thesis_amd.datasets import synthetic
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 10240

@@ -1,7 +1,7 @@
 """Quick timing probe of the hot kernels (developer tool, GPU box)."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from thesis_amd.engine import ParticleEngine
 from thesis_amd.datasets import synthetic
 

@@ -1,5 +1,5 @@
-import sys, os
-sys.path.insert(0, ".")
+import os, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import Runner, PERIOD_S
 from thesis_amd.datasets import synthetic

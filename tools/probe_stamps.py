@@ -1,9 +1,9 @@
 """Diagnostic: per-phase cycles of a map-update kernel under the bench's step (needs a stamped build:
 RBPF_STAMPS=mapray|mapfan python -m thesis_amd.build --force; RBPF_MAP_KERNEL picks the kernel).
 usage: probe_stamps.py [particles] [warm steps] [measured steps]"""
-import sys
+import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import Runner, PERIOD_S
 from thesis_amd.datasets import synthetic
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
