@@ -20,6 +20,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+# The event walk's LDS adds return their old value; for an add whose address the compiler can prove uniform (step 0 of every
+# ray: the start cell) LLVM's atomic optimizer builds a 64-iteration scan loop per wave - the LDS serialises those lanes faster.
+PER_FILE_FLAGS = {"kernels_mapev.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+
+
 def _newer(path: str, t: float) -> bool:
     return os.path.getmtime(path) > t
 
@@ -53,6 +58,7 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
         if fresh and not force and not stamped and not os.path.exists(obj + ".stamped"):
             continue
         extra = (["-DRBPF_STAMPS"] + os.environ.get("RBPF_STAMP_DEFS", "").split()) if stamped else []   # e.g. RBPF_STAMP_DEFS="-DABLATE=1"
+        extra += PER_FILE_FLAGS.get(src, [])
         jobs.append(([hipcc, *FLAGS, *extra, "-c", path, "-o", obj], obj, stamped))
 
     def run(job):

@@ -1,50 +1,38 @@
-// kernels_mapev.hip -- a5: HybridMap.update (hybridmap.py:95-145): set-up kernel + event-detecting walk (round 3).
+// kernels_mapev.hip -- a5: HybridMap.update (hybridmap.py:95-145): the event-detecting walk (round 3).
 //
-// Same exact semantics as the other map kernels (kernels_mapupdate.hip has the ordered-replay argument).  Two kernels:
+// One 1024-thread workgroup per particle, LDS window of 8-bit hit fields in GLOBAL cell-index space (as
+// kernels_mapray.hip: a ray step is pure arithmetic, the index map is folded in by the write-back).  Same exact
+// semantics as the other map kernels (kernels_mapupdate.hip has the ordered-replay argument).  What is different:
 //
-//   map_rays_kernel       256 threads per particle, three particles per CU.  Everything that is per beam or per flagged
-//                         cell and has little parallelism inside one particle, so that its latencies overlap between
-//                         particles: pose, end cells (hybridmap.py:102-113), the closed form of the reference's
-//                         Bresenham per ray (32-bit fixed-point slope), the tiles the rays enter (allocated here), the
-//                         fan's bounding box, the check of the index map's form, the 8-bit counter bound, the level
-//                         order of the rays - and the RECORDS of the flagged cells: the cells that receive an "occupied"
-//                         / "nearby" hit in this scan (the only ones whose clamped adds do not commute) are grouped by
-//                         storage cell through an LDS hash table, every cell's few events are sorted by beam, its old
-//                         value is read.  ~13 bytes per beam, ~11 per flagged cell and a header go to the second kernel
-//                         through HBM scratch.
+//   * The cells that receive an "occupied" / "nearby" hit in this scan (the only ones whose clamped adds do not commute)
+//     carry a FLAG BIT in their field before the walk starts; every add of the walk RETURNS the old field, and a step that
+//     sees the flag appends (beam, step) to an event list.  No slope buckets, no sort, no gather: a scan of 1081 beams in a
+//     room leaves ~130 such passes per particle.
+//   * Unflagged cells are written back from their counts: max(v + n * emp, min).  The flagged cells get a value from their
+//     counts too; their real value follows.
+//   * After the write-back the window's LDS is free: the flagged cells are grouped by storage cell through a hash table,
+//     each listed pass is counted into the INTERVAL between two occupied / nearby events that its beam falls into - all
+//     unoccupied passes are the same clamped add, so only their number between consecutive occupied / nearby events (in
+//     beam order) matters - and one lane per flagged cell folds emp^n0 . ev0 . emp^n1 . ev1 ... from the cell's old value
+//     and stores the byte (and its occupancy bit).
+//   * A beam's own last step (occupied) and the step before it (the pass that precedes its own "nearby" hit) are not
+//     walked at all: they are known without looking (the fold adds that pass in front of the beam's first event).
+//   * Any partition of the ray steps may be written back on its own (clamped adds of one sign compose), so a fan larger than
+//     the window is processed in strips of rows, each with its own read-modify-write.
+//   * dim need not be a multiple of 32 (0.1 m cells: dim 400): the last 32-cell group of a tile row is partial.
 //
-//   map_update_ev_kernel  1024 threads per particle, LDS window of 8-bit hit fields in GLOBAL cell-index space (as
-//                         kernels_mapray.hip: a ray step is pure arithmetic).  The flagged cells carry a flag bit in
-//                         their field before the walk starts, every add of the walk RETURNS the old field, and a step
-//                         that sees the flag appends (beam, step) to an event list - no slope buckets, no sort, no
-//                         gather.  Unflagged cells are written back from their counts as before.  After the write-back
-//                         the window's LDS is free: a hash table maps storage cells to records, every listed pass is
-//                         counted into the interval between two occupied / nearby events that its beam falls into - all
-//                         unoccupied passes are the same clamped add, so only their NUMBER between consecutive occupied
-//                         / nearby events matters - and one lane per record folds emp^n0 . ev0 . emp^n1 . ev1 ... from
-//                         the cell's old value and stores the byte (and its occupancy bit).
-//
-//   A beam's own last step (occupied) and the step before it (the pass that precedes its own "nearby" hit) are not
-//   walked at all: they are known without looking (the fold adds that pass in front of the beam's first event).
 //   Reference: hybridmap.py:95-145 (update), :274-301 (Bresenham), gridmap.py:86-117 (clamped adds).
 #include "rbpf_mapupdate.h"
 
 namespace rbpf {
 
-// diagnostic builds (RBPF_STAMPS=mapev): phase stamps of the main kernel, or with RBPF_STAMP_DEFS=-DSTAMP_PRE of the set-up kernel
-#if defined(RBPF_STAMPS) && !defined(STAMP_PRE)
+#ifdef RBPF_STAMPS
 #define STAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
-#if defined(RBPF_STAMPS) && defined(STAMP_PRE)
-#define PSTAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
-#else
-#define PSTAMP(k) do { } while (0)
-#endif
 
-static const int EB = 1024;                    // threads per particle, main kernel
-static const int PB = 256;                     // threads per particle, set-up kernel
+static const int EB = 1024;                    // threads per particle
 static const int NEAR_R = 16;                  // ray steps j < NEAR_R are counted in the 16-bit block round the start cell
 static const int LCH = 16;                     // steps per chunk of the walk beyond it
 static const int NEAR_W = 2 * NEAR_R + 1;
@@ -53,46 +41,20 @@ static const int NB_WIN = NBIN / NEAR_R + 2;   // buckets that can hold the rays
 static const int HIT_BOUND = 62;               // per direction class; two classes can meet in a cell, +1 for the flag's count bit: 125 < 128
 static const int MAXLEV = 63;                  // whole 16-step chunks per ray (reach < 1000 cells)
 static const int EVCAP = 3072;                 // passes over flagged cells kept per particle (more: exact replay of every flagged cell)
-static const int HDR = 256;                    // header ints per particle in the scratch
-enum { H_STATUS = 0, H_X0, H_Y0, H_BXL, H_BXH, H_BYL, H_BYH, H_NLEV, H_CELLS, H_NR, H_NEV, H_SLO, H_SHI, H_TLO, H_THI, H_A0, H_B0,
-       H_NK = 24, H_LP = 88 };                 // H_NK[64], H_LP[65]
+static const int NPAIR = 3;                    // pairs (beam, e) per thread kept in registers: 3 * EB pairs = 1536 beams
 
 __host__ __device__ inline int ev_al16(int x) { return (x + 15) & ~15; }
-__host__ __device__ inline int ev_fanw(int reach) { return (2 * reach + 8 + 7) & ~7; }
-
-struct EvScratch { int bpad; size_t o_fs, o_end, o_nE, o_perm, o_info, o_gxb, o_gyb, o_rkey, o_rmeta, o_roldv, o_evs, stride; };
-__host__ __device__ inline EvScratch ev_scratch(int max_beams, int reach) {
-    EvScratch s;
-    s.bpad = (max_beams + 15) & ~15;
-    const size_t fanw = (size_t)ev_fanw(reach);
-    size_t o = (size_t)HDR * 4;
-    s.o_fs = o;    o += (size_t)s.bpad * 4;
-    s.o_end = o;   o += (size_t)s.bpad * 4;
-    s.o_nE = o;    o += (size_t)s.bpad * 2;
-    s.o_perm = o;  o += (size_t)s.bpad * 2;
-    s.o_info = o;  o += (size_t)s.bpad;
-    s.o_gxb = o;   o += fanw;
-    s.o_gyb = o;   o += fanw;
-    s.o_rkey = o;  o += (size_t)s.bpad * 8;        // records: at most 2 per beam
-    s.o_rmeta = o; o += (size_t)s.bpad * 8;
-    s.o_roldv = o; o += (size_t)s.bpad * 2;
-    s.o_evs = o;   o += (size_t)s.bpad * 8;        // events + one more interval than events per record: at most 4 per beam, 16 bits
-    s.stride = (o + 255) & ~(size_t)255;
-    return s;
-}
-size_t map_update_ev_scratch_bytes(int max_beams, int reach) { return ev_scratch(max_beams, reach).stride; }
 
 struct EvGeom {
     int fanw, bpad, ncell, T, logT, E;
-    int o_mini, o_fs, o_end, o_nE, o_perm, o_info, o_gxb, o_gyb, o_gym, o_evl, o_cnt;
-    int p_keys, p_rec, p_evs, p_ic, p_bytes;                                      // the window's LDS after the write-back
-    int pre_keys, pre_cnt, pre_o2, pre_sh, pre_ux, pre_uy, pre_bytes;              // dynamic LDS of the set-up kernel
+    int o_mini, o_fs, o_end, o_nE, o_perm, o_info, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_evl, o_cnt;
+    int p_keys, p_cnta, p_offs, p_oldv, p_rlist, p_evl, p_ic, p_bytes;              // the window's LDS after the write-back
     int bytes;
     bool ok;
 };
 __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     EvGeom g;
-    g.fanw = ev_fanw(reach);
+    g.fanw = (2 * reach + 8 + 7) & ~7;
     g.bpad = (B + 3) & ~3;
     int o = 0;
     g.o_mini = o;  o += ev_al16(((NEAR_W * NEAR_W + 1) / 2) * 4);
@@ -101,6 +63,8 @@ __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     g.o_nE = o;    o += ev_al16(g.bpad * 2);
     g.o_perm = o;  o += ev_al16(g.bpad * 2);
     g.o_info = o;  o += ev_al16(g.bpad);
+    g.o_ux = o;    o += ev_al16(g.fanw * 2);
+    g.o_uy = o;    o += ev_al16(g.fanw * 2);
     g.o_gxb = o;   o += ev_al16(g.fanw);
     g.o_gyb = o;   o += ev_al16(g.fanw);
     g.o_gym = o;   o += ev_al16(g.fanw + 16);
@@ -109,26 +73,21 @@ __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     const int avail = 160 * 1024 - 2560 - o - 64;      // 2.5 KB for the kernel's static LDS
     g.ncell = avail > 0 ? avail & ~127 : 0;
     g.bytes = o + g.ncell;
-    // hash table over the flagged storage cells (at most 2 B of them)
+    // after the write-back: hash table over the flagged storage cells (at most 2 B of them)
     int T = 1024, lt = 10;
     while (T < 3 * g.bpad) { T <<= 1; ++lt; }
     g.T = T; g.logT = lt;
-    g.E = 4 * g.bpad;                                  // events (<= 2 B) + one more interval than events per cell
+    g.E = NPAIR * EB;                                  // pairs (beam, e)
     int q = 0;
-    g.p_keys = q; q += T * 4;
-    g.p_rec = q;  q += T * 2;
-    g.p_evs = q;  q += ev_al16(g.E * 2);
-    g.p_ic = q;   q += ev_al16(g.E * 2);
+    g.p_keys = q;  q += T * 4;                         // storage cell of the slot
+    g.p_cnta = q;  q += T * 4;                         // head of the slot's list of pairs
+    g.p_offs = q;  q += T * 2;                         // passes after the cell's last event
+    g.p_oldv = q;  q += T;
+    g.p_rlist = q; q += T * 2;
+    g.p_evl = q;   q += ev_al16(g.E * 2) * 2;          // next pair of the list; the lists laid out for the fold
+    g.p_ic = q;    q += ev_al16(g.E * 2);              // passes right before the pair's event
     g.p_bytes = q;
-    q = 0;
-    g.pre_keys = q; q += T * 4;
-    g.pre_cnt = q;  q += T * 4;
-    g.pre_o2 = q;   q += T * 2;
-    g.pre_sh = q;   { const int a = 2 * 8 * NBIN * 2, b = ev_al16(g.E * 2); q += a > b ? a : b; }   // slope buckets, later the unsorted events
-    g.pre_ux = q;   q += ev_al16(g.fanw * 2);
-    g.pre_uy = q;   q += ev_al16(g.fanw * 2);
-    g.pre_bytes = q;
-    g.ok = g.ncell >= 24576 && g.p_bytes <= g.ncell && B <= 4095 && reach >= NEAR_R + 4 && reach < 1000 && g.pre_bytes <= 150 * 1024;
+    g.ok = g.ncell >= 24576 && g.p_bytes <= g.ncell && 2 * 8 * NBIN * 2 <= g.ncell && 2 * B <= NPAIR * EB && reach >= NEAR_R + 4 && reach < 1000;
     return g;
 }
 
@@ -136,9 +95,20 @@ bool map_update_ev_available(const DevView& v) {
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);
     const EvGeom g = ev_geom(v.B, v.reach);
     const int gpt = (v.dim + 31) >> 5;
-    return g.ok && v.ev_scratch && v.B <= v.ev_maxb && v.dim % 8 == 0 && 3 * gpt <= 192 && v.L * v.L <= 49 && v.cc.emp < 0 && sat <= 31 &&
+    return g.ok && v.dim % 8 == 0 && 3 * gpt <= 192 && v.L * v.L <= 49 && v.cc.emp < 0 && sat <= 31 &&
            v.cc.vmax - v.cc.vmin <= 127 && v.cc.vmin <= 0 && v.cc.vmax >= 0 && v.cc.vmin >= -127 && sat * -v.cc.emp <= 127 &&
            v.cc.thr >= v.cc.vmin && v.cc.thr < v.cc.vmax;
+}
+
+// int(x / cell_size) (hybridmap.py:102,106) without the division when the product with the reciprocal is safely inside
+// a cell: x / c and x * (1 / c) differ by a few units in the last place, so they truncate alike unless an integer lies
+// within 1e-9 of the product; the division decides the rest.
+__device__ __forceinline__ int ev_cell_of(double x, double cs, double inv_cs) {
+    const double q = x * inv_cs;
+    const double t = __builtin_trunc(q);
+    const double f = q - t, af = f < 0 ? -f : f;
+    if (af > 1e-9 && af < 1.0 - 1e-9) return (int)t;
+    return trunc_to_int(x / cs);
 }
 
 // 32-bit fixed-point slope: ceil(dmin * 2^32 / dmaj), the diagonal clamped to 2^32 - 1.  With it
@@ -181,6 +151,15 @@ __device__ __forceinline__ int ev_hash_insert(uint32_t* keys, int T, int logT, u
         h = (h + 1) & (uint32_t)(T - 1);                                         // (the table has more slots than there can be keys)
     }
 }
+__device__ __forceinline__ int ev_hash_insert2(uint32_t* keys, int T, int logT, uint32_t sc, bool& created) {
+    uint32_t h = (sc * 2654435761u) >> (32 - logT);
+    for (;;) {
+        const uint32_t old = atomicCAS(&keys[h], 0xFFFFFFFFu, sc);
+        created = old == 0xFFFFFFFFu;
+        if (created || old == sc) return (int)h;
+        h = (h + 1) & (uint32_t)(T - 1);
+    }
+}
 __device__ __forceinline__ int ev_hash_find(const uint32_t* keys, int T, int logT, uint32_t sc) {
     uint32_t h = (sc * 2654435761u) >> (32 - logT);
     for (int it = 0; it < T; ++it) {
@@ -192,43 +171,57 @@ __device__ __forceinline__ int ev_hash_find(const uint32_t* keys, int T, int log
     return -1;
 }
 
-// ================================================= set-up kernel =================================================
-__global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
+// hand the particle to the window kernel (uniform over the workgroup; nothing has been written to the map yet);
+// reason codes: 1 geometry / index map, 2 counter bound
+#define EV_GIVE_BACK(reason) do { if (tid == 0) { v.mu_fallback[p] = (reason); atomicAdd(&v.stats[(reason) == 1 ? ST_FALLBACK_REASONS : ST_FB_BOUND], 1ull); } return; } while (0)
+
+__global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const EvScratch SL = ev_scratch(v.ev_maxb, v.reach);
     const EvGeom G = ev_geom(v.B, v.reach);
-    unsigned char* const sp = v.ev_scratch + (size_t)p * SL.stride;
-    int32_t* const hdr = reinterpret_cast<int32_t*>(sp);
-    uint32_t* const o_fs = reinterpret_cast<uint32_t*>(sp + SL.o_fs);
-    int32_t*  const o_end = reinterpret_cast<int32_t*>(sp + SL.o_end);
-    uint16_t* const o_nE = reinterpret_cast<uint16_t*>(sp + SL.o_nE);
-    uint16_t* const o_perm = reinterpret_cast<uint16_t*>(sp + SL.o_perm);
-    uint8_t*  const o_info = sp + SL.o_info;
-    uint32_t* const keys = reinterpret_cast<uint32_t*>(smem + G.pre_keys);   // [T] flagged storage cells
-    uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.pre_cnt);     // [T] events of the cell | fill pointer << 16
-    uint16_t* const o2 = reinterpret_cast<uint16_t*>(smem + G.pre_o2);       // [T] first event slot of the cell
-    uint16_t* const s_bins = reinterpret_cast<uint16_t*>(smem + G.pre_sh);   // [8 NBIN] rays per (class, slope bucket)
-    uint16_t* const s_far = s_bins + 8 * NBIN;                               // ... of the rays that reach the 8-bit fields
-    uint16_t* const evl = reinterpret_cast<uint16_t*>(smem + G.pre_sh);      // [E] events as they arrive (the buckets are done with by then)
-    uint16_t* const ux = reinterpret_cast<uint16_t*>(smem + G.pre_ux);       // U of global column fxl + i: every look-up below is an LDS read
-    uint16_t* const uy = reinterpret_cast<uint16_t*>(smem + G.pre_uy);
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.o_cnt);     // 8-bit fields: bit 0 = flagged, bits 1-7 = passes; [row = global x][col = global y]
+    uint8_t*  const cnt8 = smem + G.o_cnt;
+    uint32_t* const mini = reinterpret_cast<uint32_t*>(smem + G.o_mini);   // [NEAR_W^2] 16-bit fields round the start cell, same format
+    uint32_t* const r_fs = reinterpret_cast<uint32_t*>(smem + G.o_fs);     // [B] 32-bit fixed-point slope
+    int32_t*  const r_end = reinterpret_cast<int32_t*>(smem + G.o_end);    // [B] packed end cell relative to the start
+    uint16_t* const r_nE = reinterpret_cast<uint16_t*>(smem + G.o_nE);     // [B] steps the walk takes
+    uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole chunks
+    uint8_t*  const r_info = smem + G.o_info;                              // [B]
+    uint16_t* const ux = reinterpret_cast<uint16_t*>(smem + G.o_ux);       // U of global column fxl + i
+    uint16_t* const uy = reinterpret_cast<uint16_t*>(smem + G.o_uy);
+    uint8_t*  const gxb = smem + G.o_gxb;                                  // G of global column fxl + i (0 / 1)
+    uint8_t*  const gyb = smem + G.o_gyb;
+    uint8_t*  const gym = smem + G.o_gym;                                  // G of window column lc as a byte mask (0 / 0xFF)
+    uint32_t* const evlist = reinterpret_cast<uint32_t*>(smem + G.o_evl);  // [EVCAP] beam << 10 | step: passes over flagged cells
 
+    __shared__ int s_fb, s_exact;
     __shared__ int s_need[49], s_tab[49];
-    __shared__ int s_fan[4], s_fb, s_exact;
-    __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1];
+    __shared__ int s_fan[4];
+    __shared__ int s_wsum[EB / 64], s_wsum2[EB / 64];
+    __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
+    __shared__ int s_nev, s_written;
     __shared__ unsigned long long s_cells;
-    __shared__ int s_wsum[PB / 64], s_wsum2[PB / 64];
+    __shared__ double s_sincos[2];
+    __shared__ uint8_t s_ggf[192];                    // per (tile column, 32-column group): a glitched column among its 33
 
     const int LL = v.L * v.L;
     const int KW = (v.dim + WIN - 1) / WIN;
     int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
-#if defined(RBPF_STAMPS) && defined(STAMP_PRE)
+#ifdef RBPF_STAMPS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
 #endif
+    // =============================================== setup ===============================================
+    // this thread's beams: one per thread (two for the first few)
+    const int pb0 = tid, pb1 = tid + EB;
+    const double pre_x0 = pb0 < v.B ? v.bx[pb0] : 0.0, pre_y0 = pb0 < v.B ? v.by[pb0] : 0.0, pre_s0 = pb0 < v.B ? v.bscale[pb0] : 0.0;
+    const double pre_x1 = pb1 < v.B ? v.bx[pb1] : 0.0, pre_y1 = pb1 < v.B ? v.by[pb1] : 0.0, pre_s1 = pb1 < v.B ? v.bscale[pb1] : 0.0;
+    const int pre_f0 = pb0 < v.B ? v.bflags[pb0] : 0, pre_f1 = pb1 < v.B ? v.bflags[pb1] : 0;
     const double s_px = v.upd_pose[p], s_py = v.upd_pose[v.P + p];
-    double s_s, s_c;
-    sincos(v.upd_pose[2 * v.P + p], &s_s, &s_c);                              // (every lane: the same instructions as one lane)
+    if (wave == 0) {   // one wave takes the sine and cosine (a few hundred instructions); the others read them after the first barrier
+        double sn, cs_;
+        sincos(v.upd_pose[2 * v.P + p], &sn, &cs_);
+        if (lane == 0) { s_sincos[0] = sn; s_sincos[1] = cs_; }
+    }
     const int x0 = UNI(trunc_to_int(s_px / v.cs)), y0 = UNI(trunc_to_int(s_py / v.cs));   // hybridmap.py:102
     {
         int lx, ly;                                                          // hybridmap.py:98-100
@@ -237,118 +230,103 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
         const bool in_lut = lut_valid_g(v, x0 - v.reach - 2) && lut_valid_g(v, x0 + v.reach + 2) &&
                             lut_valid_g(v, y0 - v.reach - 2) && lut_valid_g(v, y0 + v.reach + 2);
         if (ok && !in_lut) { if (tid == 0) atomicCAS(v.err, 0, RBPF_ERANGE); ok = false; }
-        if (tid == 0) { v.mu_fallback[p] = 0; hdr[H_STATUS] = 0; }
+        if (tid == 0) v.mu_fallback[p] = 0;
         if (!UNI(ok)) return;
     }
-    if (tid == 0) { s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0; s_cells = 0; s_fb = 0; s_exact = 0; }
-    for (int i = tid; i < LL; i += PB) { s_need[i] = 0; s_tab[i] = tab[i]; }
-    for (int i = tid; i < 8 * NBIN; i += PB) reinterpret_cast<uint32_t*>(s_bins)[i] = 0;     // both bucket arrays
-    for (int i = tid; i < G.T; i += PB) { keys[i] = 0xFFFFFFFFu; cnt[i] = 0; }
-    if (tid <= MAXLEV) s_lcnt[tid] = 0;
-    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2;
-    for (int i = tid; i < G.fanw; i += PB) {
+    // the index map over everything a ray can reach, with a margin of two columns (the sources of a storage cell are its
+    // own global index and the next one)
+    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2, nfx = 2 * v.reach + 5;
+    for (int i = tid; i < G.fanw; i += EB) {
         const int gxq = fxl + i, gyq = fyl + i;
         const uint32_t ex = lut_valid_g(v, gxq) ? lut_at(v, gxq) : LUT_INVALID, ey = lut_valid_g(v, gyq) ? lut_at(v, gyq) : LUT_INVALID;
         ux[i] = ex != LUT_INVALID ? (uint16_t)(lut_lat(ex) * v.dim + lut_cidx(ex)) : 0xFFFFu;
         uy[i] = ey != LUT_INVALID ? (uint16_t)(lut_lat(ey) * v.dim + lut_cidx(ey)) : 0xFFFFu;
     }
-    // this thread's first beams: their loads are in flight together
-    static const int NPRE = 5;
-    double pre_x[NPRE], pre_y[NPRE], pre_sc[NPRE]; int pre_f[NPRE];
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-        const int b = tid + i * PB;
-        pre_x[i] = b < v.B ? v.bx[b] : 0.0; pre_y[i] = b < v.B ? v.by[b] : 0.0; pre_sc[i] = b < v.B ? v.bscale[b] : 0.0; pre_f[i] = b < v.B ? (int)v.bflags[b] : 0;
+    uint16_t* const s_bins = reinterpret_cast<uint16_t*>(cnt);               // [8 NBIN] rays per (class, slope bucket) (the window is not in use yet)
+    uint16_t* const s_far = s_bins + 8 * NBIN;                               // ... of the rays that reach the 8-bit fields
+    if (tid == 0) {
+        s_fan[0] = x0; s_fan[1] = x0; s_fan[2] = y0; s_fan[3] = y0;
+        s_cells = 0; s_fb = 0; s_exact = 0; s_nev = 0; s_written = 0;
     }
+    for (int i = tid; i < LL; i += EB) { s_need[i] = 0; s_tab[i] = tab[i]; }
+    for (int i = tid; i < 8 * NBIN; i += EB) reinterpret_cast<uint32_t*>(s_bins)[i] = 0;     // both bucket arrays
+    if (tid < 192) s_ggf[tid] = 0;
+    if (tid <= MAXLEV) s_lcnt[tid] = 0;
+    for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += EB) mini[i] = 0;
     __syncthreads();
-    PSTAMP(0);
+    STAMP(0);
+    const double s_s = s_sincos[0], s_c = s_sincos[1];
 
     const int C = v.R * v.dim + v.dim / 2;
-    auto U_x = [&](int g) { return (int)ux[g - fxl]; };                       // unrolled storage coordinate
-    auto U_y = [&](int g) { return (int)uy[g - fyl]; };
-    const int a0 = UNI(U_x(x0)) / v.dim, b0 = UNI(U_y(y0)) / v.dim;           // biased lattice coordinate of the start cell
-    auto lat_x = [&](int g) { const int U = U_x(g); return a0 + (U >= (a0 + 1) * v.dim ? 1 : 0) - (U < a0 * v.dim ? 1 : 0); };   // (rays are shorter than a tile)
-    auto lat_y = [&](int g) { const int U = U_y(g); return b0 + (U >= (b0 + 1) * v.dim ? 1 : 0) - (U < b0 * v.dim ? 1 : 0); };
-    // the storage cells (U_x << 16 | U_y) flagged by a beam: its end cell and, when it lies in the end cell's tile, the cell before
-    auto beam_cells = [&](int info, int x1, int y1, uint32_t& sc0, uint32_t& sc1) {
-        sc0 = sc1 = 0xFFFFFFFFu;
-        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC)) return;
-        sc0 = ((uint32_t)U_x(x1) << 16) | (uint32_t)U_y(y1);
-        if (info & RI_NEAR) sc1 = ((uint32_t)U_x(x1 + ((info >> 3) & 3) - 1) << 16) | (uint32_t)U_y(y1 + ((info >> 5) & 3) - 1);
-    };
-    // per beam: end cell, ray, tiles, level, flagged cells; what later phases need of this thread's beams stays in registers
-    unsigned long long my_cells = 0;
-    int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
-    auto beam_setup = [&](int b, double x, double y, double bsc, int bf, int32_t& end_out, int& info_out, int& nE_out) {
-        double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
-        double gy = (s_s * x + s_c * y) + s_py;
-        int x1 = trunc_to_int(gx / v.cs), y1 = trunc_to_int(gy / v.cs);        // hybridmap.py:106
-        if (bf & BF_LONG) {                                                    // hybridmap.py:107-113
-            x1 = trunc_to_int((double)x0 + bsc * (double)(x1 - x0));
-            y1 = trunc_to_int((double)y0 + bsc * (double)(y1 - y0));
-        }
-        int ddx = x1 - x0, ddy = y1 - y0;
-        if (ddx < -v.reach || ddx > v.reach || ddy < -v.reach || ddy > v.reach) {
-            atomicCAS(v.err, 0, RBPF_ERANGE);
-            ddx = 0; ddy = -1; x1 = x0; y1 = y0 - 1;                           // degenerate: no points
-        }
-        Ray r = ray_make(x0, y0, x1, y1);
-        int info = 0, nE = 0;
-        uint32_t fs = 0;
-        if (r.n > 0) {
-            info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
-            my_cells += (unsigned long long)r.n;
-            fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
-            fs = ev_fix_slope(r.dmin, r.dmaj);
-            const int a1 = lat_x(x1), b1 = lat_y(y1);
-            if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
-                const int jn = r.n - 2, mn = ev_minor(fs, jn);
-                const int nx = r.steep ? x0 + r.sx * mn : x0 + r.sx * jn, ny = r.steep ? y0 + r.sy * jn : y0 + r.sy * mn;
-                if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;          // hybridmap.py:141 same tile as the end cell
-                info |= ((nx - x1 + 1) & 3) << 3;
-                info |= ((ny - y1 + 1) & 3) << 5;
-            }
-            // tiles entered by this ray (staircase start -> [corner] -> end)
-            s_need[a0 * v.L + b0] = 1;
-            if (a1 != a0 || b1 != b0) {
-                s_need[a1 * v.L + b1] = 1;
-                if (a1 != a0 && b1 != b0) {
-                    int gxb_ = r.sx > 0 ? v.gwin[a1 * (KW + 1)] : v.gwin[a0 * (KW + 1)] - 1;
-                    int gyb_ = r.sy > 0 ? v.gwin[b1 * (KW + 1)] : v.gwin[b0 * (KW + 1)] - 1;
-                    int ox = gxb_ - x0; ox = ox < 0 ? -ox : ox;
-                    int oy = gyb_ - y0; oy = oy < 0 ? -oy : oy;
-                    int jx = r.steep ? first_j_minor_ge(r, ox) : ox;
-                    int jy = r.steep ? oy : first_j_minor_ge(r, oy);
-                    if (jx < jy) s_need[a1 * v.L + b0] = 1;
-                    else if (jy < jx) s_need[a0 * v.L + b1] = 1;
-                }
-            }
-            // steps the walk takes: all of them but the beam's own occupied step and the pass before its own nearby hit
-            nE = r.n - ((info & RI_OCC) ? 1 : 0) - ((info & RI_NEAR) ? 1 : 0);
-            const int cls = (r.steep ? 4 : 0) | (ddx > 0 ? 2 : 0) | (ddy > 0 ? 1 : 0);
-            const int key = cls * NBIN + (int)(fs >> 24);
-            atomicAdd(reinterpret_cast<unsigned int*>(s_bins) + (key >> 1), 1u << ((key & 1) * 16));
-            if (nE > NEAR_R) atomicAdd(reinterpret_cast<unsigned int*>(s_far) + (key >> 1), 1u << ((key & 1) * 16));   // only these reach the 8-bit fields
-            const int nfull = (nE - NEAR_R) / LCH;                               // whole chunks beyond the 16-bit block
-            if (nE > NEAR_R && nfull >= 1) atomicAdd(&s_lcnt[min(nfull, MAXLEV)], 1);
-            uint32_t sc0, sc1;                                                   // the beam's flagged cells: one more event each
-            beam_cells(info, x1, y1, sc0, sc1);
-            if (sc0 != 0xFFFFFFFFu) atomicAdd(&cnt[ev_hash_insert(keys, G.T, G.logT, sc0)], 1u);
-            if (sc1 != 0xFFFFFFFFu) atomicAdd(&cnt[ev_hash_insert(keys, G.T, G.logT, sc1)], 1u);
-        }
-        end_out = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
-        info_out = info; nE_out = nE;
-        o_fs[b] = fs; o_end[b] = end_out; o_nE[b] = (uint16_t)nE; o_info[b] = (uint8_t)info;
-    };
-    int32_t my_end[NPRE]; int my_info[NPRE], my_nE[NPRE];
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-        const int b = tid + i * PB;
-        my_end[i] = 0; my_info[i] = 0; my_nE[i] = 0;
-        if (b < v.B) beam_setup(b, pre_x[i], pre_y[i], pre_sc[i], pre_f[i], my_end[i], my_info[i], my_nE[i]);
-    }
-    for (int b = tid + NPRE * PB; b < v.B; b += PB) { int32_t e_; int i_, n_; beam_setup(b, v.bx[b], v.by[b], v.bscale[b], (int)v.bflags[b], e_, i_, n_); }
+    const int Uxs = UNI(ux[x0 - fxl]), Uys = UNI(uy[y0 - fyl]);
+    const int a0 = Uxs / v.dim, b0 = Uys / v.dim;
+    auto lat_x = [&](int g) { const int U = ux[g - fxl]; return a0 + (U >= (a0 + 1) * v.dim ? 1 : 0) - (U < a0 * v.dim ? 1 : 0); };   // (rays are shorter than a tile)
+    auto lat_y = [&](int g) { const int U = uy[g - fyl]; return b0 + (U >= (b0 + 1) * v.dim ? 1 : 0) - (U < b0 * v.dim ? 1 : 0); };
     {
+        unsigned long long my_cells = 0;
+        int fx0 = x0, fx1 = x0, fy0 = y0, fy1 = y0;
+        const double inv_cs = 1.0 / v.cs;
+        for (int b = tid; b < v.B; b += EB) {
+            const double x = b == pb0 ? pre_x0 : b == pb1 ? pre_x1 : v.bx[b], y = b == pb0 ? pre_y0 : b == pb1 ? pre_y1 : v.by[b];
+            const int bf = b == pb0 ? pre_f0 : b == pb1 ? pre_f1 : (int)v.bflags[b];
+            double gx = (s_c * x + (-s_s) * y) + s_px;                             // lidar.py:123
+            double gy = (s_s * x + s_c * y) + s_py;
+            int x1 = ev_cell_of(gx, v.cs, inv_cs), y1 = ev_cell_of(gy, v.cs, inv_cs);   // hybridmap.py:106
+            if (bf & BF_LONG) {                                                    // hybridmap.py:107-113
+                const double sc = b == pb0 ? pre_s0 : b == pb1 ? pre_s1 : v.bscale[b];
+                x1 = trunc_to_int((double)x0 + sc * (double)(x1 - x0));
+                y1 = trunc_to_int((double)y0 + sc * (double)(y1 - y0));
+            }
+            int ddx = x1 - x0, ddy = y1 - y0;
+            if (ddx < -v.reach || ddx > v.reach || ddy < -v.reach || ddy > v.reach) {
+                atomicCAS(v.err, 0, RBPF_ERANGE);
+                ddx = 0; ddy = -1; x1 = x0; y1 = y0 - 1;                           // degenerate: no points
+            }
+            Ray r = ray_make(x0, y0, x1, y1);
+            int info = 0, nE = 0;
+            uint32_t fs = 0;
+            if (r.n > 0) {
+                info = RI_VALID | ((bf & BF_LONG) ? 0 : RI_OCC);
+                my_cells += (unsigned long long)r.n;
+                fx0 = min(fx0, x1); fx1 = max(fx1, x1); fy0 = min(fy0, y1); fy1 = max(fy1, y1);
+                fs = ev_fix_slope(r.dmin, r.dmaj);
+                const int a1 = lat_x(x1), b1 = lat_y(y1);
+                if (r.n >= 2 && (info & RI_OCC)) {                                 // hybridmap.py:139-142
+                    const int jn = r.n - 2, mn = ev_minor(fs, jn);
+                    const int nx = r.steep ? x0 + r.sx * mn : x0 + r.sx * jn, ny = r.steep ? y0 + r.sy * jn : y0 + r.sy * mn;
+                    if (lat_x(nx) == a1 && lat_y(ny) == b1) info |= RI_NEAR;          // hybridmap.py:141 same tile as the end cell
+                    info |= ((nx - x1 + 1) & 3) << 3;
+                    info |= ((ny - y1 + 1) & 3) << 5;
+                }
+                // tiles entered by this ray (staircase start -> [corner] -> end)
+                s_need[a0 * v.L + b0] = 1;
+                if (a1 != a0 || b1 != b0) {
+                    s_need[a1 * v.L + b1] = 1;
+                    if (a1 != a0 && b1 != b0) {
+                        int gxb_ = r.sx > 0 ? v.gwin[a1 * (KW + 1)] : v.gwin[a0 * (KW + 1)] - 1;
+                        int gyb_ = r.sy > 0 ? v.gwin[b1 * (KW + 1)] : v.gwin[b0 * (KW + 1)] - 1;
+                        int ox = gxb_ - x0; ox = ox < 0 ? -ox : ox;
+                        int oy = gyb_ - y0; oy = oy < 0 ? -oy : oy;
+                        int jx = r.steep ? first_j_minor_ge(r, ox) : ox;
+                        int jy = r.steep ? oy : first_j_minor_ge(r, oy);
+                        if (jx < jy) s_need[a1 * v.L + b0] = 1;
+                        else if (jy < jx) s_need[a0 * v.L + b1] = 1;
+                    }
+                }
+                // steps the walk takes: all of them but the beam's own occupied step and the pass before its own nearby hit
+                nE = r.n - ((info & RI_OCC) ? 1 : 0) - ((info & RI_NEAR) ? 1 : 0);
+                const int cls = (r.steep ? 4 : 0) | (ddx > 0 ? 2 : 0) | (ddy > 0 ? 1 : 0);
+                const int key = cls * NBIN + (int)(fs >> 24);
+                atomicAdd(reinterpret_cast<unsigned int*>(s_bins) + (key >> 1), 1u << ((key & 1) * 16));
+                if (nE > NEAR_R) atomicAdd(reinterpret_cast<unsigned int*>(s_far) + (key >> 1), 1u << ((key & 1) * 16));   // only these reach the 8-bit fields
+                const int nfull = (nE - NEAR_R) / LCH;                               // whole chunks beyond the 16-bit block
+                if (nE > NEAR_R && nfull >= 1) atomicAdd(&s_lcnt[min(nfull, MAXLEV)], 1);
+            }
+            r_fs[b] = fs;
+            r_end[b] = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
+            r_nE[b] = (uint16_t)nE;
+            r_info[b] = (uint8_t)info;
+        }
         const int ws = wave_sum((int)my_cells);
         fx0 = wave_min(fx0); fx1 = wave_max(fx1); fy0 = wave_min(fy0); fy1 = wave_max(fy1);
         if (lane == 0) {
@@ -358,39 +336,23 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
         }
     }
     __syncthreads();
-    PSTAMP(1);
+    // ---- the window: the fan's bounding box in global cell indices; strips of storage rows if it does not fit ----
     const int bxl = UNI(s_fan[0]), bxh = UNI(s_fan[1]), byl = UNI(s_fan[2]), byh = UNI(s_fan[3]);
     // the reference's index formula over the fan (one column more on either side): U(g) = g + C - G(g) with G in {0, 1}
-    {
-        uint8_t* const o_gxb = sp + SL.o_gxb;
-        uint8_t* const o_gyb = sp + SL.o_gyb;
-        for (int i = tid; i < G.fanw; i += PB) {
-            const int gx = fxl + i, gy = fyl + i;
-            const int dxg = ux[i] != 0xFFFFu ? gx + C - (int)ux[i] : 2, dyg = uy[i] != 0xFFFFu ? gy + C - (int)uy[i] : 2;
-            if (gx >= bxl - 1 && gx <= bxh + 1 && (unsigned)dxg > 1u) s_fb = 1;   // also: the LUT ends inside the fan
-            if (gy >= byl - 1 && gy <= byh + 1 && (unsigned)dyg > 1u) s_fb = 1;
-            o_gxb[i] = (uint8_t)(dxg & 1); o_gyb[i] = (uint8_t)(dyg & 1);
-        }
+    for (int i = tid; i < G.fanw; i += EB) {
+        const int dxg = (fxl + i + C) - (int)ux[i], dyg = (fyl + i + C) - (int)uy[i];
+        if (fxl + i >= bxl - 1 && fxl + i <= bxh + 1 && (unsigned)dxg > 1u) s_fb = 1;   // also: the LUT ends inside the fan
+        if (fyl + i >= byl - 1 && fyl + i <= byh + 1 && (unsigned)dyg > 1u) s_fb = 1;
+        gxb[i] = (uint8_t)(dxg & 1); gyb[i] = (uint8_t)(dyg & 1);
     }
-    const int S_lo = U_x(bxl), S_hi = U_x(bxh), T_lo = U_y(byl), T_hi = U_y(byh);   // storage rows / columns the fan can write
-    {   // the window must hold at least 8 rows of the fan's columns
-        const int gy_base = (T_lo - C) & ~3;
-        int stride = (T_hi - C + 2 - gy_base + 3) & ~3;
-        if (((stride >> 2) & 1) == 0) stride += 4;
-        if (G.ncell / stride < 8 && tid == 0) s_fb = 1;
-    }
-    if (tid < LL && s_need[tid] && s_tab[tid] < 0) {                          // allocate missing tiles (kept zero-filled)
-        int idx = atomicSub(v.free_top, 1) - 1;
-        if (idx < 0) {
-            atomicAdd(v.free_top, 1);
-            atomicCAS(v.err, 0, RBPF_ENOMEM);
-        } else {
-            int t = v.free_stack[idx];
-            tab[tid] = t;
-            v.tile_bbox[4 * t + 0] = INT_MAX; v.tile_bbox[4 * t + 1] = -1;
-            v.tile_bbox[4 * t + 2] = INT_MAX; v.tile_bbox[4 * t + 3] = -1;
-        }
-    }
+    const int S_lo = UNI(ux[bxl - fxl]), S_hi = UNI(ux[bxh - fxl]);           // storage rows / columns the fan can write
+    const int T_lo = UNI(uy[byl - fyl]), T_hi = UNI(uy[byh - fyl]);
+    const int gy_base = (T_lo - C) & ~3;                                      // window column 0 (C is a multiple of 4)
+    int stride = (T_hi - C + 2 - gy_base + 3) & ~3;                           // columns gy_base .. T_hi - C + 1
+    if (((stride >> 2) & 1) == 0) stride += 4;                                // rows an odd number of banks apart
+    const int rows_cap = G.ncell / stride;                                    // global rows a window can hold
+    const int gpt = (v.dim + 31) >> 5;                                        // 32-cell groups per tile row (the last one may be partial)
+    const int bt_lo = T_lo / v.dim;
     if (wave == 0) {   // levels: N_k = rays with at least k whole chunks (suffix sums over the wave: MAXLEV = 63)
         const int k = lane;                                                    // lane 0 is unused (level 0 = the 16-bit block)
         const int ck = k >= 1 ? s_lcnt[k] : 0;
@@ -401,215 +363,40 @@ __global__ __launch_bounds__(PB) void map_rays_kernel(DevView v) {
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
         const unsigned long long live = __ballot(k >= 1 && suf > 0);
         const int nlev = live ? 63 - __clzll((long long)live) : 0;
-        if (k >= 1) { s_lfill[k] = suf - ck; hdr[H_NK + k] = suf; hdr[H_LP + k] = pre - nwk; }
-        if (k == 63) hdr[H_LP + 64] = pre;
-        if (k == 0) { hdr[H_NLEV] = nlev; hdr[H_NK] = 0; hdr[H_LP] = 0; }
+        if (k >= 1) { s_lfill[k] = suf - ck; s_nk[k] = suf; s_lp[k] = pre - nwk; }
+        if (k == 63) s_lp[64] = pre;
+        if (k == 0) { s_nlev = nlev; s_nk[MAXLEV + 1] = 0; }
     }
     {   // no 8-bit field can overflow: a cell at major distance j >= NEAR_R is hit, per direction class, only by rays
         // whose slope lies in a window of width 2^32 / j + 1, i.e. in at most NB_WIN consecutive buckets: bounded with all
         // rays of those buckets, or (the smaller of the two) with the rays long enough to reach an 8-bit field.
-        // inclusive prefix sums over the 2048 (class, bucket) counts, eight per thread
-        int loc[8], loc2[8], run = 0, run2 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { run += s_bins[8 * tid + i]; loc[i] = run; run2 += s_far[8 * tid + i]; loc2[i] = run2; }
-        int incl = run, incl2 = run2;
+        // inclusive prefix sums over the 2048 (class, bucket) counts, two per thread
+        const int c0 = s_bins[2 * tid], c1 = s_bins[2 * tid + 1], f0 = s_far[2 * tid], f1 = s_far[2 * tid + 1];
+        int incl = c0 + c1, incl2 = f0 + f1;
         for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64), n2 = __shfl_up(incl2, o, 64); if (lane >= o) { incl += n; incl2 += n2; } }
         if (lane == 63) { s_wsum[wave] = incl; s_wsum2[wave] = incl2; }
         __syncthreads();
-        int base = incl - run, base2 = incl2 - run2;
+        int base = incl - (c0 + c1), base2 = incl2 - (f0 + f1);
         for (int k = 0; k < wave; ++k) { base += s_wsum[k]; base2 += s_wsum2[k]; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { s_bins[8 * tid + i] = (uint16_t)(base + loc[i]); s_far[8 * tid + i] = (uint16_t)(base2 + loc2[i]); }
+        s_bins[2 * tid] = (uint16_t)(base + c0); s_bins[2 * tid + 1] = (uint16_t)(base + c0 + c1);
+        s_far[2 * tid] = (uint16_t)(base2 + f0); s_far[2 * tid + 1] = (uint16_t)(base2 + f0 + f1);
         __syncthreads();
         int mx2 = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int key = 8 * tid + i, cls = key / NBIN, bin = key % NBIN;
+        for (int i = 0; i < 2; ++i) {
+            const int key = 2 * tid + i, cls = key / NBIN, bin = key % NBIN;
             const int hi = cls * NBIN + min(bin + NB_WIN - 1, NBIN - 1);
             mx2 = max(mx2, min((int)s_bins[hi] - (key ? (int)s_bins[key - 1] : 0), (int)s_far[hi] - (key ? (int)s_far[key - 1] : 0)));
         }
         mx2 = wave_max(mx2);
         if (lane == 0 && mx2 > HIT_BOUND) s_exact = 1;
     }
-    __syncthreads();                                                          // (the buckets are done with: their place takes the events; the new tiles are in tab)
-    PSTAMP(2);
-    // ---- records of the flagged cells: index, first event slot (a cell with n events has n + 1 intervals), old value ----
-    {
-        const int per = G.T / PB;
-        int nrec = 0, nslot = 0;
-        for (int i = 0; i < per; ++i) { const int n = (int)cnt[tid * per + i]; nrec += n ? 1 : 0; nslot += n ? n + 1 : 0; }
-        int ir = nrec, is = nslot;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(ir, o, 64), t2 = __shfl_up(is, o, 64); if (lane >= o) { ir += t; is += t2; } }
-        if (lane == 63) { s_wsum[wave] = ir; s_wsum2[wave] = is; }
-        __syncthreads();
-        int r = ir - nrec, o = is - nslot, tot_r = 0, tot_s = 0;
-        for (int k = 0; k < PB / 64; ++k) { if (k < wave) { r += s_wsum[k]; o += s_wsum2[k]; } tot_r += s_wsum[k]; tot_s += s_wsum2[k]; }
-        if (tid == 0) { hdr[H_NR] = tot_r; hdr[H_NEV] = tot_s; }
-        uint32_t* const o_rkey = reinterpret_cast<uint32_t*>(sp + SL.o_rkey);
-        uint32_t* const o_rmeta = reinterpret_cast<uint32_t*>(sp + SL.o_rmeta);
-        int8_t* const o_roldv = reinterpret_cast<int8_t*>(sp + SL.o_roldv);
-        const int r_first = r;
-        for (int base = 0; base < per; base += 16) {                           // old values: sixteen loads in flight, then their stores
-            int8_t ov[16];
-            int rr = r;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int h = tid * per + base + i, n = base + i < per ? (int)cnt[h] : 0;
-                ov[i] = 0;
-                if (base + i < per) o2[h] = (uint16_t)o;
-                if (!n) continue;
-                const uint32_t key = keys[h];
-                o_rkey[r] = key; o_rmeta[r] = (uint32_t)o | ((uint32_t)n << 16);
-                // rays are shorter than a tile, the lattice coordinate moves by at most one; a tile that was missing is new: zero
-                const int sx = (int)(key >> 16), sy = (int)(key & 0xFFFFu);
-                const int a = a0 + (sx >= (a0 + 1) * v.dim ? 1 : 0) - (sx < a0 * v.dim ? 1 : 0);
-                const int bb = b0 + (sy >= (b0 + 1) * v.dim ? 1 : 0) - (sy < b0 * v.dim ? 1 : 0);
-                const int tile = ((unsigned)a < (unsigned)v.L && (unsigned)bb < (unsigned)v.L) ? s_tab[a * v.L + bb] : -1;
-                if (tile >= 0) ov[i] = v.pool[(size_t)tile * v.dim * v.dim + (size_t)(sx - a * v.dim) * v.dim + (sy - bb * v.dim)];
-                ++r; o += n + 1;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = base + i < per ? (int)cnt[tid * per + base + i] : 0;
-                if (n) o_roldv[rr++] = ov[i];
-            }
-        }
-        (void)r_first;
-    }
-    __syncthreads();
-    PSTAMP(3);
-    // every beam puts its events (pair = beam << 1 | nearby) into its cells' slots ...
-    auto put_events = [&](int b, int32_t re, int info) {
-        uint32_t sc[2];
-        beam_cells(info, x0 + (int)(int16_t)(re & 0xFFFF), y0 + (int)(int16_t)((uint32_t)re >> 16), sc[0], sc[1]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (sc[e] == 0xFFFFFFFFu) continue;
-            const int h = ev_hash_find(keys, G.T, G.logT, sc[e]);
-            const int pos = (int)(atomicAdd(&cnt[h], 1u << 16) >> 16);
-            evl[(int)o2[h] + pos] = (uint16_t)(2 * b + e);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) { const int b = tid + i * PB; if (b < v.B) put_events(b, my_end[i], my_info[i]); }
-    for (int b = tid + NPRE * PB; b < v.B; b += PB) put_events(b, o_end[b], o_info[b]);          // (written by this thread)
-    __syncthreads();
-    PSTAMP(4);
-    // ... and finds its rank among them: sorted by counting (a handful per cell)
-    uint16_t* const o_evs = reinterpret_cast<uint16_t*>(sp + SL.o_evs);
-    auto rank_events = [&](int b, int32_t re, int info) {
-        uint32_t sc[2];
-        beam_cells(info, x0 + (int)(int16_t)(re & 0xFFFF), y0 + (int)(int16_t)((uint32_t)re >> 16), sc[0], sc[1]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (sc[e] == 0xFFFFFFFFu) continue;
-            const int h = ev_hash_find(keys, G.T, G.logT, sc[e]);
-            const int o = (int)o2[h], n = (int)(cnt[h] & 0xFFFFu), pr = 2 * b + e;
-            int rank = 0;
-            for (int i = 0; i < n; ++i) rank += (int)evl[o + i] < pr;
-            o_evs[o + rank] = (uint16_t)pr;
-        }
-    };
     // rays ordered by falling count of whole chunks
-    auto put_perm = [&](int b, int nE) {
+    for (int b = tid; b < v.B; b += EB) {
+        const int nE = r_nE[b];
         const int nfull = (nE - NEAR_R) / LCH;
-        if (nE > NEAR_R && nfull >= 1) o_perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
-    };
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) { const int b = tid + i * PB; if (b < v.B) { rank_events(b, my_end[i], my_info[i]); put_perm(b, my_nE[i]); } }
-    for (int b = tid + NPRE * PB; b < v.B; b += PB) { rank_events(b, o_end[b], o_info[b]); put_perm(b, (int)o_nE[b]); }
-    PSTAMP(5);
-#if defined(RBPF_STAMPS) && defined(STAMP_PRE)
-    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
-#endif
-    if (tid == 0) {
-        const int fb = s_fb ? 1 : s_exact ? 2 : 0;
-        if (fb) {
-            v.mu_fallback[p] = fb;
-            atomicAdd(&v.stats[fb == 1 ? ST_FALLBACK_REASONS : ST_FB_BOUND], 1ull);
-        } else {
-            hdr[H_X0] = x0; hdr[H_Y0] = y0; hdr[H_BXL] = bxl; hdr[H_BXH] = bxh; hdr[H_BYL] = byl; hdr[H_BYH] = byh;
-            hdr[H_SLO] = S_lo; hdr[H_SHI] = S_hi; hdr[H_TLO] = T_lo; hdr[H_THI] = T_hi; hdr[H_A0] = a0; hdr[H_B0] = b0;
-            hdr[H_CELLS] = (int)s_cells;
-            hdr[H_STATUS] = 1;
-        }
+        if (nE > NEAR_R && nfull >= 1) perm[atomicAdd(&s_lfill[min(nfull, MAXLEV)], 1)] = (uint16_t)b;
     }
-}
-
-// ================================================== main kernel ==================================================
-__global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const EvScratch SL = ev_scratch(v.ev_maxb, v.reach);
-    const unsigned char* const sp = v.ev_scratch + (size_t)p * SL.stride;
-    const int32_t* const hdr = reinterpret_cast<const int32_t*>(sp);
-    const EvGeom G = ev_geom(v.B, v.reach);
-    uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + G.o_cnt);     // 8-bit fields: bit 0 = flagged, bits 1-7 = passes; [row = global x][col = global y]
-    uint8_t*  const cnt8 = smem + G.o_cnt;
-    uint32_t* const mini = reinterpret_cast<uint32_t*>(smem + G.o_mini);   // [NEAR_W^2] 16-bit fields round the start cell, same format
-    uint32_t* const r_fs = reinterpret_cast<uint32_t*>(smem + G.o_fs);     // [B] 32-bit fixed-point slope
-    int32_t*  const r_end = reinterpret_cast<int32_t*>(smem + G.o_end);    // [B] packed end cell relative to the start
-    uint16_t* const r_nE = reinterpret_cast<uint16_t*>(smem + G.o_nE);     // [B] steps the walk takes
-    uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole chunks
-    uint8_t*  const r_info = smem + G.o_info;                              // [B]
-    uint8_t*  const gxb = smem + G.o_gxb;                                  // G of global column fxl + i (0 / 1)
-    uint8_t*  const gyb = smem + G.o_gyb;
-    uint8_t*  const gym = smem + G.o_gym;                                  // G of window column lc as a byte mask (0 / 0xFF)
-    uint32_t* const evlist = reinterpret_cast<uint32_t*>(smem + G.o_evl);  // [EVCAP] beam << 10 | step: passes over flagged cells
-
-    __shared__ int s_tab[49];
-    __shared__ int s_hdr[H_LP + MAXLEV + 3];
-    int* const s_nk = s_hdr + H_NK;                   // [MAXLEV + 1] rays with at least k whole chunks
-    int* const s_lp = s_hdr + H_LP;                   // [MAXLEV + 2] first wave-item of level k
-    __shared__ int s_nev, s_written;
-    __shared__ uint8_t s_ggf[192];                    // per (tile column, 32-column group): a glitched column among its 33
-
-    const int LL = v.L * v.L;
-    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
-#if defined(RBPF_STAMPS) && !defined(STAMP_PRE)
-    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
-#endif
-    // ====================== staging (one round trip: no address below depends on a loaded value) ======================
-    {
-        const uint32_t* g_fs = reinterpret_cast<const uint32_t*>(sp + SL.o_fs);
-        const int32_t* g_end = reinterpret_cast<const int32_t*>(sp + SL.o_end);
-        const uint16_t* g_nE = reinterpret_cast<const uint16_t*>(sp + SL.o_nE);
-        const uint16_t* g_perm = reinterpret_cast<const uint16_t*>(sp + SL.o_perm);
-        const uint8_t* g_info = sp + SL.o_info;
-        for (int b = tid; b < v.B; b += EB) { r_fs[b] = g_fs[b]; r_end[b] = g_end[b]; r_nE[b] = g_nE[b]; r_info[b] = g_info[b]; perm[b] = g_perm[b]; }
-        const uint32_t* g_gxb = reinterpret_cast<const uint32_t*>(sp + SL.o_gxb);
-        const uint32_t* g_gyb = reinterpret_cast<const uint32_t*>(sp + SL.o_gyb);
-        for (int i = tid; i < G.fanw / 4; i += EB) { reinterpret_cast<uint32_t*>(gxb)[i] = g_gxb[i]; reinterpret_cast<uint32_t*>(gyb)[i] = g_gyb[i]; }
-        for (int i = tid; i < LL; i += EB) s_tab[i] = tab[i];
-        if (tid < H_LP + MAXLEV + 2) s_hdr[tid] = hdr[tid];
-        if (tid == 0) { s_nev = 0; s_written = 0; }
-        if (tid < 192) s_ggf[tid] = 0;
-        for (int i = tid; i < (NEAR_W * NEAR_W + 1) / 2; i += EB) mini[i] = 0;
-    }
-    const uint32_t* const g_rkey = reinterpret_cast<const uint32_t*>(sp + SL.o_rkey);
-    const uint32_t* const g_rmeta = reinterpret_cast<const uint32_t*>(sp + SL.o_rmeta);
-    const int8_t* const g_roldv = reinterpret_cast<const int8_t*>(sp + SL.o_roldv);
-    const uint16_t* const g_evs = reinterpret_cast<const uint16_t*>(sp + SL.o_evs);
-    // this thread's records (two per thread cover 2048; more: the loops below read the rest from memory); loaded whatever
-    // the record count turns out to be
-    const int rcap = 2 * SL.bpad - 1;
-    const uint32_t my_key0 = g_rkey[min(tid, rcap)], my_key1 = g_rkey[min(tid + EB, rcap)];
-    __syncthreads();
-    if (UNI(s_hdr[H_STATUS]) != 1) return;
-    const int x0 = UNI(s_hdr[H_X0]), y0 = UNI(s_hdr[H_Y0]);
-    const int nlev = UNI(s_hdr[H_NLEV]), NR = UNI(s_hdr[H_NR]), NEV = UNI(s_hdr[H_NEV]);
-    const int S_lo = UNI(s_hdr[H_SLO]), S_hi = UNI(s_hdr[H_SHI]), T_lo = UNI(s_hdr[H_TLO]), T_hi = UNI(s_hdr[H_THI]);   // storage rows / columns the fan can write
-    const int a0 = UNI(s_hdr[H_A0]), b0 = UNI(s_hdr[H_B0]);
-    STAMP(0);
-
-    const int fxl = x0 - v.reach - 2, fyl = y0 - v.reach - 2, nfx = 2 * v.reach + 5;
-    const int C = v.R * v.dim + v.dim / 2;
-    const int gy_base = (T_lo - C) & ~3;                                      // window column 0 (C is a multiple of 4)
-    int stride = (T_hi - C + 2 - gy_base + 3) & ~3;                           // columns gy_base .. T_hi - C + 1
-    if (((stride >> 2) & 1) == 0) stride += 4;                                // rows an odd number of banks apart
-    const int rows_cap = G.ncell / stride;                                    // global rows a window can hold (>= 8: checked by the set-up kernel)
-    const int gpt = (v.dim + 31) >> 5;                                        // 32-cell groups per tile row (the last one may be partial)
-    const int bt_lo = T_lo / v.dim;
     for (int lc = tid; lc < stride + 16 && lc < G.fanw + 16; lc += EB) {       // column glitch mask in window coordinates
         const int i = lc + gy_base - fyl;
         const bool gl = i >= 0 && i < nfx && gyb[i];
@@ -621,7 +408,34 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             if ((t & 31) < 4 && (unsigned)(idx - 1) < 192u) s_ggf[idx - 1] = 1;   // (gt = 0: the last group of the tile before)
         }
     }
+    __syncthreads();
+    if (UNI(s_fb) || rows_cap < 8) { EV_GIVE_BACK(1); }
+    if (UNI(s_exact)) { EV_GIVE_BACK(2); }
+    if (tid < LL && s_need[tid] && s_tab[tid] < 0) {                          // allocate missing tiles (kept zero-filled)
+        int idx = atomicSub(v.free_top, 1) - 1;
+        if (idx < 0) {
+            atomicAdd(v.free_top, 1);
+            atomicCAS(v.err, 0, RBPF_ENOMEM);
+        } else {
+            int t = v.free_stack[idx];
+            s_tab[tid] = t;                                                    // (a new tile's cells are zero: an old value read through either state of the table is 0)
+            tab[tid] = t;
+            v.tile_bbox[4 * t + 0] = INT_MAX; v.tile_bbox[4 * t + 1] = -1;
+            v.tile_bbox[4 * t + 2] = INT_MAX; v.tile_bbox[4 * t + 3] = -1;
+        }
+    }
+    STAMP(1);
 
+    // the storage cell (U_x << 16 | U_y) flagged by pair (beam, e): the beam's end cell (e = 0) or the cell before it (e = 1,
+    // only when it lies in the end cell's tile); ~0 = none
+    auto pair_cell = [&](int pr) -> uint32_t {
+        const int b = pr >> 1, info = r_info[b];
+        if ((info & (RI_VALID | RI_OCC)) != (RI_VALID | RI_OCC) || ((pr & 1) && !(info & RI_NEAR))) return 0xFFFFFFFFu;
+        const int32_t re = r_end[b];
+        int x1 = x0 + (int)(int16_t)(re & 0xFFFF), y1 = y0 + (int)(int16_t)((uint32_t)re >> 16);
+        if (pr & 1) { x1 += ((info >> 3) & 3) - 1; y1 += ((info >> 5) & 3) - 1; }
+        return ((uint32_t)ux[x1 - fxl] << 16) | (uint32_t)uy[y1 - fyl];
+    };
     struct FCell { int sx, sy; int gx0, gx1, gy0, gy1; int ngx, ngy; };            // storage cell and its source global cells
     auto cell_sources = [&](uint32_t sc, FCell& f) {
         f.sx = (int)(sc >> 16); f.sy = (int)(sc & 0xFFFFu);
@@ -649,6 +463,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);        // passes that saturate any cell: 20
     const uint32_t satb = (uint32_t)sat * 0x01010101u, sadd = (128u - (uint32_t)sat) * 0x01010101u;
     const int cnt_lds = ev_lds_addr(cnt), mini_lds = ev_lds_addr(mini);
+    const int nlev = UNI(s_nlev);
     // a lane's steps that met a flagged cell (bit 16 + u of m = step j0 + u): into the event list
     auto log_events = [&](uint32_t m, int b, int j0, int ev_lo, int ev_hi, int gx_base, bool filter) {
         while (m) {
@@ -664,6 +479,20 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             if (pos < EVCAP) evlist[pos] = ((uint32_t)b << 10) | (uint32_t)j;
         }
     };
+    // this thread's pairs (beam, e): pair = tid, tid + EB, tid + 2 EB; cell and old value stay in registers until the
+    // flagged cells are folded (the old value must be read before the write-back)
+    uint32_t my_sc[NPAIR]; int my_old[NPAIR];
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+        const int pr = tid + i * EB;
+        my_sc[i] = pr < 2 * v.B ? pair_cell(pr) : 0xFFFFFFFFu;
+        my_old[i] = 0;
+        if (my_sc[i] != 0xFFFFFFFFu) {
+            int tile, row_t, col_t;
+            cell_addr((int)(my_sc[i] >> 16), (int)(my_sc[i] & 0xFFFFu), tile, row_t, col_t);
+            if (tile >= 0) my_old[i] = (int)v.pool[(size_t)tile * v.dim * v.dim + (size_t)row_t * v.dim + col_t];   // (in flight until the fold)
+        }
+    }
 
     // =============================================== windows ==============================================
     int n_win = 0;
@@ -671,7 +500,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         const int S1 = min(S_hi, S0 + rows_cap - 2);                             // storage rows S0..S1
         const int gx_base = S0 - C, rows_w = S1 - S0 + 2;                        // global rows gx_base .. gx_base + rows_w - 1
         const bool whole = S0 == S_lo && S1 == S_hi;                             // one window holds the fan
-        BAR_LDS();                                                               // the previous window is done with the counters
+        BAR_LDS();                                                               // the previous window (or the slope buckets) is done with the counters
         {
             uint4* c4 = reinterpret_cast<uint4*>(cnt);
             const int n16 = (rows_w * stride + 15) >> 4;
@@ -680,8 +509,10 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         BAR_LDS();
         // ---- flags: every global cell that maps to a storage cell with an occupied / nearby hit; the flag comes with a
         //      count of one, so a flagged field is never zero (the write-back takes "touched" from the field) ----
-        for (int r = tid; r < NR; r += EB) {
-            const uint32_t sc = r == tid ? my_key0 : r == tid + EB ? my_key1 : g_rkey[r];
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+            const uint32_t sc = my_sc[i];
+            if (sc == 0xFFFFFFFFu) continue;
             FCell f;
             cell_sources(sc, f);
 #pragma unroll
@@ -700,7 +531,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             }
         }
         BAR_LDS();
-        STAMP(1);
+        STAMP(2);
         // rows of this window whose passes are reported from here (the first and the last global row belong to two strips)
         const int ev_lo = (!whole && gxb[gx_base - fxl]) ? 1 : 0, ev_hi = (!whole && !gxb[gx_base + rows_w - 1 - fxl]) ? rows_w - 2 : rows_w - 1;
         // ---- the 16-bit block: steps 0 .. NEAR_R - 1 of every ray, once ----
@@ -743,14 +574,15 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
             // the next item's ray is fetched while this one's adds are in flight
             int k = 1, kn = 1;
+            int lp_c = UNI(s_lp[1]), lp_n = UNI(s_lp[2]), nk_c = UNI(s_nk[1]);    // first item of the level, of the next level; rays of the level
             int nb = -1; uint32_t nfs = 0; int32_t nend = 0;
             auto fetch_item = [&](int q) {
                 nb = -1;
                 if (q >= nitems) return;
-                while (kn < nlev && q >= UNI(s_lp[kn + 1])) ++kn;
-                const int nk = UNI(s_nk[kn]), nwk = (nk + 63) >> 6, wslot = q - UNI(s_lp[kn]);
+                while (kn < nlev && q >= lp_n) { ++kn; lp_c = lp_n; lp_n = UNI(s_lp[kn + 1]); nk_c = UNI(s_nk[kn]); }
+                const int nwk = (nk_c + 63) >> 6, wslot = q - lp_c;
                 const int ii = lane * nwk + wslot;
-                if (ii < nk) { nb = perm[ii]; nfs = r_fs[nb]; nend = r_end[nb]; }
+                if (ii < nk_c) { nb = perm[ii]; nfs = r_fs[nb]; nend = r_end[nb]; }
             };
             fetch_item(wave);
             for (int q = wave; q < nitems; q += EB / 64) {
@@ -778,6 +610,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                     }
                     fetch_item(q + EB / 64);
                     __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): one wait, then the sixteen answers
 #pragma unroll
                     for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit(ret[u] >> (sh[u] & 31), m, 1);
                 } else {
@@ -833,7 +666,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             }
         }
         BAR_LDS();
-        STAMP(2);
+        STAMP(3);
         // ---- the 16-bit block's counts go into the window (saturated: only min(n, sat) matters for an unflagged cell;
         //      a flagged one arrives with its count of one and stays "touched") ----
         for (int mi = tid; mi < NEAR_W * NEAR_W; mi += EB) {
@@ -843,7 +676,6 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             if (f) cnt8[row * stride + col] = (uint8_t)(min(f, (uint32_t)sat) << 1);
         }
         BAR_LDS();
-        STAMP(3);
         // ---- write-back: one read-modify-write per touched 32-cell group of storage cells, tile by tile.  Storage cell s
         //      receives global cell s - C where that one is not glitched plus global cell s - C + 1 where that one is.  The
         //      flagged cells get a value from their counts like all others; their real value follows after the windows. ----
@@ -964,49 +796,51 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         }
         STAMP(4);
     }
-    // this thread's records again: their event slots, their old values; the sorted events (all in flight across the barriers)
-    const uint32_t my_meta0 = tid < NR ? g_rmeta[tid] : 0u, my_meta1 = tid + EB < NR ? g_rmeta[tid + EB] : 0u;
-    const int my_old0 = tid < NR ? (int)g_roldv[tid] : 0, my_old1 = tid + EB < NR ? (int)g_roldv[tid + EB] : 0;
-    const int nevw = (NEV + 1) / 2;
-    const uint32_t my_ev0 = tid < nevw ? reinterpret_cast<const uint32_t*>(g_evs)[tid] : 0u, my_ev1 = tid + EB < nevw ? reinterpret_cast<const uint32_t*>(g_evs)[tid + EB] : 0u;
     BAR_LDS();                                                                // the window's LDS is free (the write-back's stores are still on their way)
 
     // ======================================== flagged cells ========================================
     uint32_t* const keys = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_keys);    // [T] storage cell, ~0 = empty
-    uint16_t* const rec = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_rec);      // [T] record of the slot's cell
-    uint16_t* const evs = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_evs);      // [E] events (pair = beam << 1 | nearby), sorted per record
-    uint32_t* const ic32 = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_ic);      // [E] 16-bit pass counts of the intervals
-    const uint16_t* const ic16 = reinterpret_cast<const uint16_t*>(ic32);
+    uint32_t* const head = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_cnta);    // [T] first pair of the cell's list, 0xFFFF = none
+    uint16_t* const iclast = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_offs);  // [T] passes after the cell's last event
+    int8_t*   const oldc = reinterpret_cast<int8_t*>(smem + G.o_cnt + G.p_oldv);      // [T] the cell's value before the scan
+    uint16_t* const rlist = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_rlist);  // [records] slots in use
+    uint16_t* const nextp = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_evl);    // [pairs] next pair (beam << 1 | nearby) on the same cell
+    uint16_t* const evl = nextp + ev_al16(G.E * 2) / 2;                               // [pairs] the lists, one after the other (laid out by the fold)
+    uint16_t* const ic16 = reinterpret_cast<uint16_t*>(smem + G.o_cnt + G.p_ic);      // [pairs] passes right before the pair's event
     const int T = G.T;
     const int nev_all = UNI(s_nev);
     const bool overflow = nev_all > EVCAP;
-    for (int i = tid; i < T; i += EB) keys[i] = 0xFFFFFFFFu;
-    for (int i = tid; i < nevw; i += EB) { ic32[i] = 0; reinterpret_cast<uint32_t*>(evs)[i] = i == tid ? my_ev0 : i == tid + EB ? my_ev1 : reinterpret_cast<const uint32_t*>(g_evs)[i]; }
+    for (int i = tid; i < T / 4; i += EB) { reinterpret_cast<uint4*>(keys)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); reinterpret_cast<uint4*>(head)[i] = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu); }
+    for (int i = tid; i < T / 8; i += EB) reinterpret_cast<uint4*>(iclast)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < ev_al16(G.E * 2) / 16; i += EB) reinterpret_cast<uint4*>(ic16)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { s_wsum[0] = 0; s_wsum[1] = 0; }
     BAR_LDS();
-    for (int r = tid; r < NR; r += EB) {
-        const uint32_t sc = r == tid ? my_key0 : r == tid + EB ? my_key1 : g_rkey[r];
-        rec[ev_hash_insert(keys, T, G.logT, sc)] = (uint16_t)r;
+    // every pair joins the list of its cell (the cell's first pair lists the cell and leaves its old value)
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+        if (my_sc[i] == 0xFFFFFFFFu) continue;
+        bool created;
+        const int h = ev_hash_insert2(keys, T, G.logT, my_sc[i], created);
+        if (created) { rlist[atomicAdd(&s_wsum[1], 1)] = (uint16_t)h; oldc[h] = (int8_t)my_old[i]; }
+        nextp[tid + i * EB] = (uint16_t)atomicExch(&head[h], (uint32_t)(tid + i * EB));
     }
     BAR_LDS();
     STAMP(5);
     if (!overflow) {
-        // every listed pass goes into the interval its beam falls into: the number of events of smaller beams (a beam's
-        // own passes come before its own occupied / nearby hit)
+        // every listed pass is counted in front of the first event of a beam that is not smaller than its own (a beam's own
+        // passes come before its own occupied / nearby hit), or behind the cell's last event
         for (int e = tid; e < nev_all; e += EB) {
             const uint32_t ev = evlist[e];
             const int b = (int)(ev >> 10), j = (int)(ev & 1023u);
             const RayDir d = ray_dir(b);
             const int mn = ev_minor(r_fs[b], j);
             const int gx = x0 + d.sx * (d.steep ? mn : j), gy = y0 + d.sy * (d.steep ? j : mn);
-            const int Ux = gx + C - (int)gxb[gx - fxl], Uy = gy + C - (int)gyb[gy - fyl];
-            const int h = ev_hash_find(keys, T, G.logT, ((uint32_t)Ux << 16) | (uint32_t)Uy);
+            const int h = ev_hash_find(keys, T, G.logT, ((uint32_t)ux[gx - fxl] << 16) | (uint32_t)uy[gy - fyl]);
             if (h < 0) continue;                                                 // (cannot happen: only flagged fields report)
-            const uint32_t of = g_rmeta[rec[h]];
-            const int o2 = (int)(of & 0xFFFFu), n = (int)(of >> 16);
-            int lo = 0, hi = n;                                                  // first event of a beam >= b
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (((int)evs[o2 + mid] >> 1) < b) lo = mid + 1; else hi = mid; }
-            const int at = o2 + lo;
-            atomicAdd(&ic32[at >> 1], 1u << ((at & 1) * 16));
+            int best = 0xFFFF;
+            for (int m = (int)head[h]; m != 0xFFFF; m = nextp[m]) if (m >= 2 * b && m < best) best = m;
+            uint16_t* const slot = best != 0xFFFF ? &ic16[best] : &iclast[h];
+            atomicAdd(reinterpret_cast<unsigned int*>(reinterpret_cast<uintptr_t>(slot) & ~(uintptr_t)3), (reinterpret_cast<uintptr_t>(slot) & 2) ? 0x10000u : 1u);
         }
     }
     __syncthreads();                                                          // every store of the write-back has landed: the flagged cells' bytes follow
@@ -1020,46 +854,54 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         uint32_t* ow = &v.occ[((size_t)tile * v.dim + row_t) * v.ow + (col_t >> 5)];
         if (val > v.cc.thr) atomicOr(ow, 1u << (col_t & 31)); else atomicAnd(ow, ~(1u << (col_t & 31)));
     };
+    const int NR = UNI(s_wsum[1]);
     if (!overflow) {
         for (int r = tid; r < NR; r += EB) {
-            const uint32_t key = r == tid ? my_key0 : r == tid + EB ? my_key1 : g_rkey[r];
-            const uint32_t of = r == tid ? my_meta0 : r == tid + EB ? my_meta1 : g_rmeta[r];
-            int val = r == tid ? my_old0 : r == tid + EB ? my_old1 : (int)g_roldv[r];
-            const int o2 = (int)(of & 0xFFFFu), n = (int)(of >> 16);
-            int prev_beam = -1;
+            const int h = rlist[r];
+            int val = (int)oldc[h];
+            // the cell's pairs, laid out one after the other
+            int n = 0;
+            for (int m = (int)head[h]; m != 0xFFFF; m = nextp[m]) ++n;
+            const int o2 = atomicAdd(&s_wsum[0], n);
+            { int i = 0; for (int m = (int)head[h]; m != 0xFFFF; m = nextp[m]) evl[o2 + i++] = (uint16_t)m; }
+            // the events in ascending (beam, nearby) order: the smallest one above the last, n times (a handful per cell)
+            int cur = -2;
             for (int i = 0; i < n; ++i) {
-                const int ek = evs[o2 + i], beam = ek >> 1;
+                int ek = 0x7FFFFFFF, nx = 0x7FFFFFFF;                                 // the next event and the one after it
+                for (int q = 0; q < n; ++q) { const int e = evl[o2 + q]; if (e > cur) { if (e < ek) { nx = ek; ek = e; } else if (e < nx) nx = e; } }
+                const int beam = ek >> 1;
                 // the beam's own pass over the cell before its nearby hit is not in the list: it precedes the beam's first event here
-                const bool has_near = (ek & 1) || (i + 1 < n && (int)evs[o2 + i + 1] == ek + 1);
-                const int np = (int)ic16[o2 + i] + ((beam != prev_beam && has_near) ? 1 : 0);
+                const bool has_near = (ek & 1) || nx == ek + 1;
+                const int np = (int)ic16[ek] + ((beam != (cur >> 1) && has_near) ? 1 : 0);
                 val = max(val + min(np, sat) * v.cc.emp, v.cc.vmin);              // gridmap.py:97-101, np times
                 val = min(val + ((ek & 1) ? v.cc.nearby : v.cc.occ), v.cc.vmax);  // gridmap.py:86-90 / 108-112
-                prev_beam = beam;
+                cur = ek;
             }
-            val = max(val + min((int)ic16[o2 + n], sat) * v.cc.emp, v.cc.vmin);
-            store_cell(key, val);
+            val = max(val + min((int)iclast[h], sat) * v.cc.emp, v.cc.vmin);
+            store_cell(keys[h], val);
         }
     } else {
         // more passes over flagged cells than the list holds: every flagged cell is replayed by a wave with the exact
         // closed-form membership test over all beams (rbpf_mapupdate.h), whatever the list says
         for (int r = wave; r < NR; r += EB / 64) {
-            const uint32_t key = g_rkey[r];
+            const int h = rlist[r];
+            const uint32_t key = keys[h];
             FCell f;
             cell_sources(key, f);
             const int gxc[2] = {f.gx0, f.gx1}, gyc[2] = {f.gy0, f.gy1};
-            const int val = replay_cell_wave(v, r_info, r_end, x0, y0, gxc, f.ngx, gyc, f.ngy, (int)g_roldv[r], lane);
+            const int val = replay_cell_wave(v, r_info, r_end, x0, y0, gxc, f.ngx, gyc, f.ngy, (int)oldc[h], lane);
             if (lane == 0) store_cell(key, val);
         }
         if (tid == 0) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)NR);
     }
     STAMP(7);
     if (tid == 0) {
-        atomicAdd(&v.stats[ST_RAY_CELLS], (unsigned long long)s_hdr[H_CELLS]);
+        if (s_cells) atomicAdd(&v.stats[ST_RAY_CELLS], s_cells);
         if (s_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_written);
         atomicAdd(&v.stats[ST_MAP_WINDOWS], (unsigned long long)n_win);
         atomicAdd(&v.stats[ST_MAP_EVENTS], (unsigned long long)nev_all);
         if (overflow) atomicAdd(&v.stats[ST_EV_OVERFLOWS], 1ull);
-#if defined(RBPF_STAMPS) && !defined(STAMP_PRE)
+#ifdef RBPF_STAMPS
         for (int k = 0; k < 8; ++k) atomicAdd(&v.stats[8 + k], (unsigned long long)st_acc[k]);
 #endif
     }
@@ -1067,10 +909,8 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
 
 void launch_map_update_ev(const DevView& v, hipStream_t s) {
     const EvGeom g = ev_geom(v.B, v.reach);
-    static size_t lds_set[MAX_DEVICES] = {}, lds_set_pre[MAX_DEVICES] = {};
+    static size_t lds_set[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_ev_kernel), (size_t)g.bytes, lds_set);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(map_rays_kernel), (size_t)g.pre_bytes, lds_set_pre);
-    hipLaunchKernelGGL(map_rays_kernel, dim3(v.P), dim3(PB), (size_t)g.pre_bytes, s, v);
     hipLaunchKernelGGL(map_update_ev_kernel, dim3(v.P), dim3(EB), (size_t)g.bytes, s, v);
 }
 

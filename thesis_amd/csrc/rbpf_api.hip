@@ -241,9 +241,6 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.stats, ST_COUNT); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
         ALLOC(h, v.mu_hint, 6); HIP_TRY(h, hipMemset(v.mu_hint, 0, 6 * 4));
-        v.ev_maxb = c.max_beams;
-        ALLOC(h, v.ev_scratch, P * map_update_ev_scratch_bytes(c.max_beams, v.reach));
-        HIP_TRY(h, hipMemset(v.ev_scratch, 0, P * map_update_ev_scratch_bytes(c.max_beams, v.reach)));
         ALLOC(h, h->d_did_early, 1);
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only

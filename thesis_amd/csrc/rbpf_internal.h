@@ -68,11 +68,9 @@ struct DevView {
     int32_t* mu_fallback;              // [P] != 0: the map-update kernel that ran first gave the particle back to the next one
     int32_t* mu_hint;                  // [3][2] (attempts, geometry give-backs) of the whole-fan kernel's last launches, rotating by step
     int mu_step;                       // launch counter of the map update (selects the mu_hint slot)
-    int mu_mode;                       // 0 = event-walk kernel pair (kernels_mapev.hip), then 128x128 windows for what it gave back;
+    int mu_mode;                       // 0 = event-walk kernel (kernels_mapev.hip), then 128x128 windows for what it gave back;
                                        // 1 = 128x128 windows only; 2 = whole-fan kernel, then windows; 3 = global-index kernel
                                        // (kernels_mapray.hip), then windows; 4 = whole-fan, global-index, windows; 5 = as 0, explicitly
-    unsigned char* ev_scratch;         // [P][map_update_ev_scratch_bytes(ev_maxb)] header + per-ray tables from map_rays_kernel to map_update_ev_kernel
-    int ev_maxb;                       // the beam count the scratch was sized for (rbpf_config.max_beams)
     uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
     int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
     int32_t* dup_of; int dups_valid;    // representative of each particle's group of exact duplicates since the last resample (kernels_resample.hip); valid until the next proposal
@@ -162,7 +160,6 @@ void launch_map_update_fan(const DevView& v, hipStream_t s);
 bool map_update_ray_available(const DevView& v);
 void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s);
 bool map_update_ev_available(const DevView& v);
-size_t map_update_ev_scratch_bytes(int max_beams, int reach);
 void launch_map_update_ev(const DevView& v, hipStream_t s);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
