@@ -117,69 +117,26 @@ __global__ __launch_bounds__(64) void propose_prep_kernel(DevView v, ProposeArgs
     o[21] = -0.5 * ((double)rank * 1.8378770664093453 + log_pdet);   // log(2*pi)
 }
 
-__global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
-    __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
-    __shared__ int s_sum[KMAX];
-    __shared__ float4 s_q[KMAX];                       // single-precision sample frame in home-tile cells: (cos, sin) / cell, offset x, y
-    __shared__ int s_tab[49];
-    __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
-    __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
-    __shared__ double s_mom[16];                       // moments: mean[3], norm, sig[9], min_w
-    __shared__ int s_bad;
-    const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
-    const int LL = v.L * v.L;
-    {   // the frame propose_prep_kernel left
-        const double* pr = v.prop_prep + (size_t)p * PREP_W;
-        if (tid < 9) { s_U[tid / 3][tid % 3] = pr[tid]; s_A[tid / 3][tid % 3] = pr[9 + tid]; }
-        if (tid < 3) s_mean[tid] = pr[18 + tid];
-        if (tid == 0) { s_logc = pr[21]; s_bad = pr[22] != 0.0; }
-    }
-    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
-    for (int i = tid; i < LL; i += BLOCK) {
-        const int t = tab[i];
-        s_tab[i] = t;
-        s_base[i] = t >= 0 ? (unsigned long long)t * (unsigned long long)v.dim * (unsigned long long)v.dim : ~0ull;
-    }
-    __syncthreads();
-    if (s_bad) {
-        if (tid == 0) { v.upd_pose[p] = v.px[p]; v.upd_pose[v.P + p] = v.py[p]; v.upd_pose[2 * v.P + p] = v.pth[p]; }
-        return;
-    }
-    const HomeTile home = home_tile(v, s_tab, s_mean[0], s_mean[1]);
+// ---- weighting: K gathers per beam (robot.py:118-139).  The samples of a beam end on neighbouring cells (one or two cache
+//      lines), so a beam's K look-ups are done together, eight at a time: eight cell addresses in the particle's home tile
+//      are formed without a branch, the eight byte loads are issued back to back, then added - nothing waits on a single
+//      load.  The address comes from SINGLE-precision arithmetic in home-tile cell coordinates.  Error budget, in cells,
+//      for |rotated beam| <= 1.5 dim and |result| < dim: the conversions of x, y, cos / cell, sin / cell cost
+//      4 * 1.5 dim * 2^-24, the offset's rounding dim * 2^-24, the two fused multiply-adds 2.5 dim * 2^-24 and
+//      dim * 2^-24: 9.5 dim * 2^-24 = 4.5e-4 at dim = 800, 1.2e-3 at 2048.  The address is taken only when the point lies
+//      more than WSAFE (1e-3 for dim <= 1024, else 2e-3) inside its cell on both axes: the cell index is then the
+//      reference's (gridmap.py:119-128 on the float64 point).  The other 0.4 - 0.8 % of the look-ups are redone in float64
+//      the reference's way (lookup_cell_home) once the beam's fast ones are out.
+//      Shared by propose_weight_kernel (every scan step) and weight_samples_product_kernel (rbpf_weight_samples: the
+//      per-sample test entry), so that the tests of the entry are tests of the product's look-ups.
+struct WeightFrame {
+    const double* s_c; const double* s_s; const double (*s_g)[3]; const float4* s_q; int* s_sum;
+    const int* s_tab; const unsigned long long* s_base;
+};
+__device__ __forceinline__ void weight_beams(const DevView& v, const HomeTile& home, const WeightFrame& f, int K, int tid) {
+    const double* const s_c = f.s_c; const double* const s_s = f.s_s; const double (*s_g)[3] = f.s_g; const float4* const s_q = f.s_q;
+    int* const s_sum = f.s_sum; const int* const s_tab = f.s_tab; const unsigned long long* const s_base = f.s_base;
     const double inv_cs = (double)v.dim / v.tile_len;
-    if (tid < K) {
-        double g[3];
-        if (a.guesses) {
-            const double* gp = a.guesses + ((size_t)p * K + tid) * 3;
-            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
-        } else {
-            double z[3];
-            normals3(a.seed, a.stream, (uint32_t)v.global_id[p], (uint32_t)tid, z);
-            for (int i = 0; i < 3; ++i) g[i] = s_mean[i] + ((s_A[i][0] * z[0] + s_A[i][1] * z[1]) + s_A[i][2] * z[2]);
-        }
-        // robot.py:87: pdf = exp(-0.5 * (rank*log(2pi) + log_pdet + maha)) * 10
-        double d0 = g[0] - s_mean[0], d1 = g[1] - s_mean[1], d2 = g[2] - s_mean[2];
-        double maha = 0.0;
-        for (int j = 0; j < 3; ++j) { double t = (d0 * s_U[0][j] + d1 * s_U[1][j]) + d2 * s_U[2][j]; maha += t * t; }
-        s_pr[tid] = exp(s_logc - 0.5 * maha) * 10;
-        double sn, cs;
-        sincos(g[2], &sn, &cs);
-        s_c[tid] = cs; s_s[tid] = sn; s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
-        s_q[tid] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(g[0] * inv_cs + (double)home.off_x), (float)(g[1] * inv_cs + (double)home.off_y));
-        s_sum[tid] = 0;
-    }
-    __syncthreads();
-
-    // ---- weighting: K gathers per beam.  The samples of a beam end on neighbouring cells (one or two cache lines), so
-    //      a beam's K look-ups are done together, eight at a time: eight cell addresses in the particle's home tile are
-    //      formed without a branch, the eight byte loads are issued back to back, then added - nothing waits on a single
-    //      load.  The address comes from SINGLE-precision arithmetic in home-tile cell coordinates.  Error budget, in
-    //      cells, for |rotated beam| <= 1.5 dim and |result| < dim: the conversions of x, y, cos / cell, sin / cell cost
-    //      4 * 1.5 dim * 2^-24, the offset's rounding dim * 2^-24, the two fused multiply-adds 2.5 dim * 2^-24 and
-    //      dim * 2^-24: 9.5 dim * 2^-24 = 4.5e-4 at dim = 800, 1.2e-3 at 2048.  The address is taken only when the point
-    //      lies more than WSAFE (1e-3 for dim <= 1024, else 2e-3) inside its cell on both axes: the cell index is then the
-    //      reference's (gridmap.py:119-128 on the float64 point).  The other 0.4 - 0.8 % of the look-ups are redone in
-    //      float64 the reference's way (lookup_cell_home) once the beam's fast ones are out. -------------------------
     // (the home tile's address is the same for the whole workgroup: kept in scalar registers, so that a look-up is a
     // 32-bit offset from a scalar base - no 64-bit address arithmetic per load)
     typedef __attribute__((address_space(1))) const int8_t global_i8;
@@ -189,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hb), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hb >> 32));
         hbase = (const global_i8*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
     }
-    const float WSAFE = v.dim <= 1024 ? 1e-3f : 2e-3f;
+    const float WSAFE = v.wsafe_override >= 0.0f ? v.wsafe_override : (v.dim <= 1024 ? 1e-3f : 2e-3f);   // (the override is a test knob: RBPF_WSAFE)
     const bool f32_ok = home.ok && v.dim <= 2048;
     // Work split: four lanes share a beam, each takes eight of the (up to 32) samples; 64 beams per pass of the workgroup.
     // 1081 beams are 17 passes with the last one 89 % full (a thread per beam and all samples: 5 passes, the last 22 %
@@ -243,6 +200,65 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
             if ((tid & 63) < 4 && k0 + u < K) atomicAdd(&s_sum[k0 + u], s);
         }
     }
+}
+
+__global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
+    __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3], s_pr[KMAX], s_w[KMAX];
+    __shared__ int s_sum[KMAX];
+    __shared__ float4 s_q[KMAX];                       // single-precision sample frame in home-tile cells: (cos, sin) / cell, offset x, y
+    __shared__ int s_tab[49];
+    __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
+    __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
+    __shared__ double s_mom[16];                       // moments: mean[3], norm, sig[9], min_w
+    __shared__ int s_bad;
+    const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
+    const int LL = v.L * v.L;
+    {   // the frame propose_prep_kernel left
+        const double* pr = v.prop_prep + (size_t)p * PREP_W;
+        if (tid < 9) { s_U[tid / 3][tid % 3] = pr[tid]; s_A[tid / 3][tid % 3] = pr[9 + tid]; }
+        if (tid < 3) s_mean[tid] = pr[18 + tid];
+        if (tid == 0) { s_logc = pr[21]; s_bad = pr[22] != 0.0; }
+    }
+    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+    for (int i = tid; i < LL; i += BLOCK) {
+        const int t = tab[i];
+        s_tab[i] = t;
+        s_base[i] = t >= 0 ? (unsigned long long)t * (unsigned long long)v.dim * (unsigned long long)v.dim : ~0ull;
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) { v.upd_pose[p] = v.px[p]; v.upd_pose[v.P + p] = v.py[p]; v.upd_pose[2 * v.P + p] = v.pth[p]; }
+        return;
+    }
+    const HomeTile home = home_tile(v, s_tab, s_mean[0], s_mean[1]);
+    const double inv_cs = (double)v.dim / v.tile_len;
+    if (tid < K) {
+        double g[3];
+        if (a.guesses) {
+            const double* gp = a.guesses + ((size_t)p * K + tid) * 3;
+            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+        } else {
+            double z[3];
+            normals3(a.seed, a.stream, (uint32_t)v.global_id[p], (uint32_t)tid, z);
+            for (int i = 0; i < 3; ++i) g[i] = s_mean[i] + ((s_A[i][0] * z[0] + s_A[i][1] * z[1]) + s_A[i][2] * z[2]);
+        }
+        // robot.py:87: pdf = exp(-0.5 * (rank*log(2pi) + log_pdet + maha)) * 10
+        double d0 = g[0] - s_mean[0], d1 = g[1] - s_mean[1], d2 = g[2] - s_mean[2];
+        double maha = 0.0;
+        for (int j = 0; j < 3; ++j) { double t = (d0 * s_U[0][j] + d1 * s_U[1][j]) + d2 * s_U[2][j]; maha += t * t; }
+        s_pr[tid] = exp(s_logc - 0.5 * maha) * 10;
+        double sn, cs;
+        sincos(g[2], &sn, &cs);
+        s_c[tid] = cs; s_s[tid] = sn; s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
+        s_q[tid] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(g[0] * inv_cs + (double)home.off_x), (float)(g[1] * inv_cs + (double)home.off_y));
+        s_sum[tid] = 0;
+    }
+    __syncthreads();
+
+    {
+        const WeightFrame wf{s_c, s_s, s_g, s_q, s_sum, s_tab, s_base};
+        weight_beams(v, home, wf, K, tid);
+    }
     __syncthreads();
     if (tid < K) {
         double obs = v.inv_quantum > 0 ? (v.inv_quantum + (double)s_sum[tid]) / v.inv_quantum
@@ -282,6 +298,50 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
             v.upd_pose[p] = mean0; v.upd_pose[v.P + p] = mean1; v.upd_pose[2 * v.P + p] = mean2;   // robot.py:115
         }
     }
+}
+
+// rbpf_weight_samples (test entry for a4): explicit sample poses and motion probabilities, the PRODUCT's look-ups.  The
+// home tile is the tile of the first sample pose (the product takes the tile of the matcher's pose).
+__global__ __launch_bounds__(BLOCK) void weight_samples_product_kernel(DevView v, const double* __restrict__ guesses,
+                                                                       const double* __restrict__ prs, int K, double* __restrict__ out_w) {
+    __shared__ double s_c[KMAX], s_s[KMAX], s_g[KMAX][3];
+    __shared__ int s_sum[KMAX];
+    __shared__ float4 s_q[KMAX];
+    __shared__ int s_tab[49];
+    __shared__ unsigned long long s_base[49];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int LL = v.L * v.L;
+    const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
+    for (int i = tid; i < LL; i += BLOCK) {
+        const int t = tab[i];
+        s_tab[i] = t;
+        s_base[i] = t >= 0 ? (unsigned long long)t * (unsigned long long)v.dim * (unsigned long long)v.dim : ~0ull;
+    }
+    __syncthreads();
+    const double* g0 = guesses + (size_t)p * K * 3;
+    const HomeTile home = home_tile(v, s_tab, g0[0], g0[1]);
+    const double inv_cs = (double)v.dim / v.tile_len;
+    if (tid < K) {
+        const double* gp = guesses + ((size_t)p * K + tid) * 3;
+        double sn, cs;
+        sincos(gp[2], &sn, &cs);
+        s_c[tid] = cs; s_s[tid] = sn; s_g[tid][0] = gp[0]; s_g[tid][1] = gp[1]; s_g[tid][2] = gp[2];
+        s_q[tid] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(gp[0] * inv_cs + (double)home.off_x), (float)(gp[1] * inv_cs + (double)home.off_y));
+        s_sum[tid] = 0;
+    }
+    __syncthreads();
+    {
+        const WeightFrame wf{s_c, s_s, s_g, s_q, s_sum, s_tab, s_base};
+        weight_beams(v, home, wf, K, tid);
+    }
+    __syncthreads();
+    if (tid < K) {
+        double obs = v.inv_quantum > 0 ? (v.inv_quantum + (double)s_sum[tid]) / v.inv_quantum : 1.0 + (double)s_sum[tid] * v.quantum;
+        out_w[(size_t)p * K + tid] = obs * prs[(size_t)p * K + tid];
+    }
+}
+void launch_weight_samples_product(const DevView& v, const double* d_guesses, const double* d_prs, int K, double* d_out_w, hipStream_t s) {
+    hipLaunchKernelGGL(weight_samples_product_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, d_guesses, d_prs, K, d_out_w);
 }
 
 // robot.py:75-77 for particles on the NaN branch: weight += (1 + sum log-odds at the latest pose) * 1,

@@ -254,6 +254,10 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
                         (mk && std::string(mk) == "ev") ? 5 : 0;
             const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
             v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
+            const char* ws = getenv("RBPF_WSAFE");          // test knob: the weighting's guard band in cells (0 shows what the band is for)
+            v.wsafe_override = ws ? (float)atof(ws) : -1.0f;
+            const char* we = getenv("RBPF_WEIGHT_ENTRY");   // "f64": rbpf_weight_samples runs the float64 kernel (comparison)
+            v.weight_entry_f64 = (we && std::string(we) == "f64") ? 1 : 0;
             v.ndt_refine = h->cfg.ndt_refine;
             const char* dd = getenv("RBPF_MATCH_DEDUP");     // "0": every particle runs the matcher, duplicates included (tests)
             h->dedup_enabled = !(dd && std::string(dd) == "0");
@@ -542,7 +546,8 @@ int rbpf_weight_samples(rbpf_handle* h, const double* guesses, const double* prs
     HIP_TRY(h, hipMemcpyAsync(h->d_guess, guesses, n * 3 * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_prs, prs, n * 8, hipMemcpyHostToDevice, h->stream));
     h->prof_begin(1);
-    launch_weight_samples(h->v, h->d_guess, h->d_prs, K, h->d_w, h->stream);
+    if (h->v.weight_entry_f64 || K > 32) launch_weight_samples(h->v, h->d_guess, h->d_prs, K, h->d_w, h->stream);
+    else launch_weight_samples_product(h->v, h->d_guess, h->d_prs, K, h->d_w, h->stream);   // the look-ups of every scan step (kernels_propose.hip)
     h->prof_end(1);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out_w, h->d_w, n * 8, hipMemcpyDeviceToHost, h->stream));

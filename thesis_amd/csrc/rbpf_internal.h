@@ -74,6 +74,8 @@ struct DevView {
     uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
     int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
     int32_t* dup_of; int dups_valid;    // representative of each particle's group of exact duplicates since the last resample (kernels_resample.hip); valid until the next proposal
+    float wsafe_override;              // >= 0: the weighting's guard band in cells (RBPF_WSAFE, a test knob); < 0: the built-in value
+    int weight_entry_f64;              // 1: rbpf_weight_samples runs the float64 kernel of round 1 (RBPF_WEIGHT_ENTRY=f64) instead of the product's look-ups
     int match_stage_slow;              // 1 = the matcher stages its field bit by bit (RBPF_MATCH_STAGE=slow; the check of the fast path)
     unsigned long long* stats;         // [8] device counters
     int32_t* err;                      // [1] sticky device error code
@@ -151,6 +153,7 @@ namespace rbpf {
 // kernel launchers (one translation unit per kernel family)
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
+void launch_weight_samples_product(const DevView& v, const double* d_guesses, const double* d_prs, int K, double* d_out_w, hipStream_t s);
 void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s);   // picks the kernel(s) below; d_bad: NaN-branch weight increments after the update (or nullptr)
 void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s);   // bytes rounded up to 16
 void launch_ingest2(const int32_t* mapped_a, int32_t* d_a, const int32_t* mapped_b, int32_t* d_b, int n, hipStream_t s);
