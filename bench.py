@@ -110,7 +110,9 @@ class Runner:
         self.frame += 1
 
 
-KERNEL_NAMES = {"raycast": "rbpf::map_update_ray_kernel",        # (the family's other kernel - 128x128 windows - exits at once when the first gave nothing back) "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
+# the dominant kernel of every timed family (the map update's other kernel - 128x128 windows - exits at once when the first
+# gave nothing back)
+KERNEL_NAMES = {"raycast": "rbpf::map_update_ev_kernel", "match": "rbpf::match_kernel", "ndt": "rbpf::ndt_kernel",
                 "weight": "rbpf::propose_weight_kernel", "resample": "rbpf::resample_copy_kernel"}
 
 
@@ -258,6 +260,7 @@ def main():
     # is where the per-kernel table comes from and how the dominant kernel is found); the timed region brackets only
     # the dominant one, whose live duration the roofline needs.
     FAMILIES = ("raycast", "weight", "resample", "match", "ndt")
+    assert set(KERNEL_NAMES) == set(FAMILIES), "every timed kernel family needs its dominant kernel's symbol"
     run.e.set_profiling(True)
     for _ in range(args.warmup):
         run.step()
@@ -328,7 +331,7 @@ def main():
                 "step_frac": step_ach / (HBM_PEAK_GBS * world),
                 "step_bytes_per_particle_update": bytes_pu,
                 "window_fallbacks_per_particle_step": c["window_fallbacks"] / n_fb,
-                "fast_kernel_give_backs_per_particle_step": sum((int(c["fallback_reasons"]) >> (16 * i)) & 0xFFFF for i in range(4)) / n_fb,
+                "fast_kernel_give_backs_per_particle_step": (int(c["fallback_geometry"]) + int(c["fallback_bound"]) + int(c["fallback_tables"])) / n_fb,
                 "global_index_kernel_windows_per_particle_step": c["map_windows"] / n_fb,
                 "algorithmic_bytes_per_particle_update": alg_bytes[dominant],
                 "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,

@@ -81,7 +81,7 @@ def _run_config(P, B, cs, fov, steps_checked, steps_total, probe):
     ms = e.kernel_ms("raycast")
     out = {"particles": P, "beams": B, "cell_size": cs, "steps": n,
            "window_fallbacks_per_particle_step": c["window_fallbacks"] / (P * n),
-           "fast_kernel_give_backs_per_particle_step": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / (P * n),
+           "fast_kernel_give_backs_per_particle_step": (c["fallback_geometry"] + c["fallback_bound"] + c["fallback_tables"]) / (P * n),
            "ray_kernel_windows_per_particle_step": c["map_windows"] / (P * n),
            "tiles_in_use": c["tiles_in_use"], "map_update_ms_mean": float(ms[1:].mean()) if len(ms) > 1 else None,
            "median_position_error_m": float(err)}
@@ -119,7 +119,7 @@ def test_intel_head_fallback_fraction(cs):
     n = 64 * max(1, c["scan_updates"])
     out = {"accepted_scans": res.accepted, "map_updates": c["scan_updates"],
            "window_fallbacks_per_particle_update": c["window_fallbacks"] / n,
-           "fast_kernel_give_backs_per_particle_update": sum((c["fallback_reasons"] >> (16 * i)) & 0xFFFF for i in range(4)) / n,
+           "fast_kernel_give_backs_per_particle_update": (c["fallback_geometry"] + c["fallback_bound"] + c["fallback_tables"]) / n,
            "ray_kernel_windows_per_particle_update": c["map_windows"] / n}
     _report(f"intel_head cs={cs}", out)
     pf.close()
@@ -127,12 +127,11 @@ def test_intel_head_fallback_fraction(cs):
         assert out["window_fallbacks_per_particle_update"] <= 0.02
 
 
-def test_fans_too_large_for_the_whole_fan_kernel_go_to_the_global_index_kernel(monkeypatch):
-    """15 m rays all round at 0.05 m: 600-cell fans, twice the whole-fan kernel's window, with all three kernels in a row
-    (RBPF_MAP_KERNEL=chain).  The first launch finds that out per particle after its setup; from the second launch on the
-    whole-fan kernel leaves the particles to the global-index kernel at once (every 16th still tries: `mu_hint`).
+def test_fans_larger_than_the_lds_window_run_in_strips(monkeypatch):
+    """15 m rays all round at 0.05 m: 600-cell fans, three times what the event-walk kernel's LDS window holds: the fan is
+    processed in strips of rows inside the one launch (any partition of the ray steps may be written back on its own).
     Cell-exact against the C oracle for a few particles, no particle reaches the 128x128-window kernel."""
-    monkeypatch.setenv("RBPF_MAP_KERNEL", "chain")
+    monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
     from thesis_amd.engine import ParticleEngine
     P, B = 96, 721
     ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
@@ -158,7 +157,6 @@ def test_fans_too_large_for_the_whole_fan_kernel_go_to_the_global_index_kernel(m
         assert set(got) == set(want)
         for cc in want:
             assert np.array_equal(got[cc], want[cc]), f"particle {p} tile {cc}"
-    geometry = c["fallback_reasons"] & 0xFFFF
-    assert c["window_fallbacks"] == 0 and geometry == P * n_scans            # every particle left the whole-fan kernel every time ...
-    assert c["map_windows"] >= 2 * P * n_scans                               # ... and needed several strips in the global-index kernel
+    assert c["window_fallbacks"] == 0 and c["fallback_geometry"] == 0 and c["fallback_bound"] == 0
+    assert c["map_windows"] >= 2 * P * n_scans                               # several strips per particle and scan
     e.close()

@@ -18,18 +18,17 @@ def eng_mod():
 
 
 def select_map_kernel(monkeypatch, name):
-    """"auto" = the default chain (global-index kernel, then windows for what it gives back); "chain" = whole-fan kernel,
-    global-index kernel, windows in a row; "ray" / "fan" / "window" run only that kernel (and windows for what it gives
-    back), through RBPF_MAP_KERNEL, which rbpf_create reads."""
+    """"auto" = the default chain (event-walk kernel, then windows for what it gives back); "ray" = the global-index kernel
+    of round 2 first; "window" = the 128x128-window kernel alone - through RBPF_MAP_KERNEL, which rbpf_create reads."""
     if name == "auto":
         monkeypatch.delenv("RBPF_MAP_KERNEL", raising=False)
     else:
         monkeypatch.setenv("RBPF_MAP_KERNEL", name)
 
 
-@pytest.fixture(params=["auto", "chain", "fan", "window"])
+@pytest.fixture(params=["auto", "ray", "window"])
 def map_kernel(request, monkeypatch):
-    """The default chain (= the global-index kernel first), all three kernels in a row, the whole-fan and the window kernel on their own."""
+    """The default chain (= the event-walk kernel first), the global-index kernel first, the window kernel on its own."""
     select_map_kernel(monkeypatch, request.param)
     return request.param
 
@@ -143,12 +142,12 @@ def test_map_update_random_particles_vs_oracle(eng_mod, map_kernel):
     e.close()
 
 
-@pytest.mark.parametrize("kernel", ["auto", "chain", "fan"])
+@pytest.mark.parametrize("kernel", ["auto", "ray"])
 @pytest.mark.parametrize("scene", ["near_wall", "one_direction", "tile_corner", "negative_side", "short_rays"])
-def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
-    """Inputs chosen against the whole-fan kernel's layout limits: cells hit by more rays than an 8-bit field may
-    hold (the particle is handed to the window kernel), fans that straddle four tiles, the irregular stretch of
-    the reference's index formula on the negative side, many flagged cells.  Cell-exact against the oracle."""
+def test_map_update_first_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
+    """Inputs chosen against the first kernels' layout limits: cells hit by more rays than an 8-bit field may hold (the
+    particle is handed to the window kernel), fans that straddle four tiles, the irregular stretch of the reference's
+    index formula on the negative side, many flagged cells and many passes over them.  Cell-exact against the oracle."""
     from thesis_amd.datasets import synthetic
     select_map_kernel(monkeypatch, kernel)
     rng = np.random.Generator(np.random.PCG64(77))
@@ -183,12 +182,12 @@ def test_map_update_fan_kernel_hard_cases(eng_mod, monkeypatch, scene, kernel):
         assert_tiles_equal(e, p, oracle_dump(maps[p]), e.dim)
     c = e.counters()
     assert c["ray_cells_visited"] == sum(m.cells_visited for m in maps)
-    if scene == "near_wall" and kernel == "auto":
-        assert c["window_fallbacks"] == 0                   # up to 256 rays per slope bucket, dozens of events per wall cell: still the first kernel
+    if scene == "near_wall":
+        assert c["window_fallbacks"] == 0                   # dozens of events per wall cell, thousands of passes over flagged cells: still the first kernel
     if scene == "one_direction":
         assert c["window_fallbacks"] == P * len(scans)      # the 8-bit guard must have fired for every particle
-    if scene == "tile_corner":          # at most a particle or two over the event table; the rest ran in the four-tile window
-        assert c["window_fallbacks"] <= (2 if kernel == "fan" else 0), "fallback reasons %x" % c["fallback_reasons"]
+    if scene == "tile_corner":          # the four-tile fan stays in the first kernel
+        assert c["window_fallbacks"] == 0, "fallback reasons %x" % c["fallback_reasons"]
     if scene == "negative_side":        # only the third scan (independent random ranges: cells with dozens of events) may fall back
         assert c["window_fallbacks"] <= P, "fallback reasons %x" % c["fallback_reasons"]
     e.close()
@@ -510,8 +509,8 @@ def test_map_update_extreme_beam_counts(eng_mod, B):
 @pytest.mark.parametrize("B,cs", [(1081, 0.05), (1200, 0.015625)])
 def test_map_update_many_long_beams_in_strips(eng_mod, map_kernel, B, cs):
     """Beams of 14.9 m all round: a 600-cell fan at 0.05 m and a 1900-cell one at 1/64 m - several strips of the
-    global-index kernel.  At 1/64 m the 1200 rays have more than 65 535 whole 16-step chunks, so the strips walk level by
-    level instead of through 16-bit item prefixes.  Second scan: 11 m.  Cell-exact against the C oracle; no particle reaches
+    first kernel (at 1/64 m the 1200 rays have more than 65 535 whole 16-step chunks: the global-index kernel's strips then walk
+    level by level instead of through 16-bit item prefixes).  Second scan: 11 m.  Cell-exact against the C oracle; no particle reaches
     the window kernel by default."""
     from oracle import c_oracle
     ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
@@ -565,7 +564,7 @@ def test_map_update_on_a_lattice_line_known_deviation(eng_mod):
         e.close()
 
 
-@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "auto"), (0.1, 180, "window"), (0.05, 721, "fan"), (0.025, 181, "ray"), (0.1, 180, "chain"), (0.05, 361, "auto")])
+@pytest.mark.parametrize("cs,B,kernel", [(0.05, 181, "auto"), (0.1, 180, "window"), (0.05, 721, "ray"), (0.025, 181, "ray"), (0.1, 180, "auto"), (0.05, 361, "auto")])
 def test_closed_loop_population_equals_oracle(eng_mod, monkeypatch, cs, B, kernel):
     """(Cell sizes of configs C1, C2 and C5, both map-update kernels.)  The whole per-scan cycle of main.py:138-214 over several scans, engine against a population of OracleRobot:
     IMU propagation, Robot.map_update with the engine seam doubled (matcher result and proposal samples injected on both

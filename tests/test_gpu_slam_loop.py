@@ -1,5 +1,6 @@
 """The reference's main loop (main.py:138-214) over the engine: BASELINE config C1 (Intel log, 64 particles,
-0.1 m grid, native 180 beams) on the first scans of data/intel.txt (a data fixture, tests/golden/intel_head.log)."""
+0.1 m grid, native 180 beams) on data/intel.txt (data fixtures: tests/golden/intel_head.log = its first scans,
+tests/golden/intel.txt.gz = the whole log, 910 scans, compressed)."""
 import os
 
 import numpy as np
@@ -28,6 +29,32 @@ def test_intel_replay_c1():
     traj = pf.trajectory(0)
     assert len(traj) > 70 and np.all(np.isfinite(np.array(traj)))
     assert pf.particles[0]._map.get_odds_at((0.0, 0.0)) is not None
+    pf.close()
+
+
+def test_intel_replay_c1_whole_log():
+    """BASELINE configs[0] in full: all 910 scans of data/intel.txt (14 541 ODOM records) through run_log with 64
+    particles at 0.1 m cells (dim 400: the first map kernel's last 32-cell group of a tile row is partial), the
+    absolute-pose model of IntelIMUData.py:23-36.  The reference itself cannot replay this file (its cursors stall at the
+    first duplicated 0.1 s tick, tests/test_host_logic.py); checked here: every record is consumed, the state stays
+    finite, the particles stay on the odometry track, the map grows over several tiles and no particle leaves the first
+    map kernel."""
+    from thesis_amd.datasets.carmen import load_carmen
+    from thesis_amd.slam import ParticleFilter, run_log
+    log = load_carmen(os.path.join(HERE, "golden", "intel.txt.gz"))
+    assert log.scans.shape == (910, 180) and len(log.odom) == 14541
+    pf = ParticleFilter(64, log.angles, motion_model="absolute", cell_size=0.1, keep_history=False, pool_tiles=64 * 20)
+    res = run_log(pf, log.scans, log.scan_times, log.odom, log.odom_times, order=log.order)
+    assert res.frames == 910 and sum(1 for ev in res.trace if ev[0] == "imu") == 14541 and res.accepted >= 300
+    poses = pf.engine.poses()
+    assert np.all(np.isfinite(poses)) and np.all(np.isfinite(pf.engine.weights()))
+    assert np.all(np.linalg.norm(poses[:, :2] - log.odom[-1, :2], axis=1) < 3.0)
+    c = pf.engine.counters()
+    assert c["window_fallbacks"] <= 0.01 * 64 * res.accepted, (c["window_fallbacks"], c["fallback_geometry"], c["fallback_bound"])
+    tiles = pf.engine.tiles(0)
+    assert len(tiles) >= 2 and sum(int(np.count_nonzero(t)) for _, t in tiles) > 20000
+    xs, ys = pf.particles[0]._map.get_occupied_points()
+    assert len(xs) > 2000
     pf.close()
 
 
@@ -83,10 +110,10 @@ def test_checkpoint_continues_bit_identically(tmp_path):
     a.close(); b.close()
 
 
-def test_long_run_fan_kernel_equals_window_kernel(monkeypatch):
+def test_long_run_first_kernel_equals_window_kernel(monkeypatch):
     """120 steps of the full pipeline (matcher, proposal, map update, resample) on two engines that differ only in the
-    map-update kernel (whole-fan vs 128x128 windows): states after every step and all maps at the end are identical.
-    The fan kernel's rare paths (fallback to windows, deep buckets, NaN branch) all leave the result unchanged."""
+    map-update kernel (event-walk kernel vs 128x128 windows): states after every step and all maps at the end are identical.
+    The first kernel's rare paths (fallback to windows, full event list, NaN branch) all leave the result unchanged."""
     from thesis_amd import engine
     from thesis_amd.datasets import synthetic
     P, B, T = 192, 1081, 120

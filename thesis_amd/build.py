@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librbpf_hip.so")
-SOURCES = ["rbpf_api.hip", "kernels_weight.hip", "kernels_mapupdate.hip", "kernels_mapfan.hip", "kernels_mapray.hip", "kernels_mapev.hip", "kernels_state.hip",
+SOURCES = ["rbpf_api.hip", "kernels_weight.hip", "kernels_mapupdate.hip", "kernels_mapray.hip", "kernels_mapev.hip", "kernels_state.hip",
            "kernels_propose.hip", "kernels_resample.hip", "kernels_match.hip", "kernels_inputs.hip"]
 HEADERS = ["rbpf_internal.h", "rbpf_math.h", "rbpf_device.h", "rbpf_mapupdate.h", os.path.join("..", "..", "include", "rbpf_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
@@ -46,7 +46,7 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    stamp_target = os.environ.get("RBPF_STAMPS", "")   # diagnostic builds: per-phase cycle stamps in ONE kernel file (mapfan | mapupdate | mapray | match)
+    stamp_target = os.environ.get("RBPF_STAMPS", "")   # diagnostic builds: per-phase cycle stamps in ONE kernel file (mapev | mapupdate | mapray | match)
     common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:

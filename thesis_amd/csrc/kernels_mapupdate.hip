@@ -720,16 +720,10 @@ void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t
     size_t lds = raycast_lds_bytes(v.B, v.reach);
     static size_t lds_set[MAX_DEVICES] = {};   // more than the default 64 KiB of dynamic LDS
     ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_kernel), lds, lds_set);
-    // the chain: every kernel leaves mu_fallback[p] != 0 for the particles it could not hold
-    bool first = false;
-    const bool ev_ok = (v.mu_mode == 0 || v.mu_mode == 5) && map_update_ev_available(v);
-    const bool ray_ok = map_update_ray_available(v);
-    if (ev_ok) { launch_map_update_ev(v, s); first = true; }
-    else {
-        if ((v.mu_mode == 2 || v.mu_mode == 4 || (v.mu_mode == 0 && !ray_ok)) && map_update_fan_available(v)) { launch_map_update_fan(v, s); first = true; }
-        if ((v.mu_mode == 0 || v.mu_mode == 3 || v.mu_mode == 4) && ray_ok) { launch_map_update_ray(v, first ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, s); first = true; }
-    }
-    const bool fan = first;
+    // the chain: the first kernel leaves mu_fallback[p] != 0 for the particles it could not hold, the window kernel takes those
+    bool fan = false;
+    if ((v.mu_mode == 0 || v.mu_mode == 5) && map_update_ev_available(v)) { launch_map_update_ev(v, s); fan = true; }
+    else if ((v.mu_mode == 0 || v.mu_mode == 3) && map_update_ray_available(v)) { launch_map_update_ray(v, nullptr, s); fan = true; }
     hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, d_bad);
 }
 

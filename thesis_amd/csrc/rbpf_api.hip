@@ -240,18 +240,15 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.prop_prep, 24 * P);
         ALLOC(h, v.stats, ST_COUNT); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
-        ALLOC(h, v.mu_hint, 6); HIP_TRY(h, hipMemset(v.mu_hint, 0, 6 * 4));
         ALLOC(h, h->d_did_early, 1);
         HIP_TRY(h, hipMemset(h->d_did_early, 0, 4));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_early, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming | hipEventDisableSystemFence));
-        {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle, =fan / =ray run only that kernel
-            // (and windows behind it), =chain runs all three in a row
-            // before it (tests, comparisons); default: whole-fan kernel, global-index kernel for the fans it cannot hold
+        {   // RBPF_MAP_KERNEL=window keeps the 128x128-window map update for every particle, =ray / =ev run that first kernel (and
+            // windows behind it); default: the event-walk kernel, windows for what it gives back (tests, comparisons)
             const char* mk = getenv("RBPF_MAP_KERNEL");
-            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : (mk && std::string(mk) == "fan") ? 2 : (mk && std::string(mk) == "ray") ? 3 : (mk && std::string(mk) == "chain") ? 4 :
-                        (mk && std::string(mk) == "ev") ? 5 : 0;
+            v.mu_mode = (mk && std::string(mk) == "window") ? 1 : (mk && std::string(mk) == "ray") ? 3 : (mk && std::string(mk) == "ev") ? 5 : 0;
             const char* ms = getenv("RBPF_MATCH_STAGE");    // "slow": the matcher's field is staged bit by bit (tests)
             v.match_stage_slow = (ms && std::string(ms) == "slow") ? 1 : 0;
             const char* ws = getenv("RBPF_WSAFE");          // test knob: the weighting's guard band in cells (0 shows what the band is for)
@@ -560,7 +557,6 @@ static int run_map_update(rbpf_handle* h, const uint8_t* d_bad = nullptr) {
     h->prof_begin(0);
     launch_map_update_fused(v, d_bad, h->stream);
     h->prof_end(0);
-    v.mu_step++;
     HIP_TRY(h, hipGetLastError());
     h->scan_updates++;
     return RBPF_OK;

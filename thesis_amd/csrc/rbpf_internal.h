@@ -66,11 +66,9 @@ struct DevView {
     double*  upd_pose;                 // [3][P] poses used by the current map update
     double*  prop_prep;                // [P][24] proposal frame of the current scan update (kernels_propose.hip: U, A, mean, log c)
     int32_t* mu_fallback;              // [P] != 0: the map-update kernel that ran first gave the particle back to the next one
-    int32_t* mu_hint;                  // [3][2] (attempts, geometry give-backs) of the whole-fan kernel's last launches, rotating by step
-    int mu_step;                       // launch counter of the map update (selects the mu_hint slot)
-    int mu_mode;                       // 0 = event-walk kernel (kernels_mapev.hip), then 128x128 windows for what it gave back;
-                                       // 1 = 128x128 windows only; 2 = whole-fan kernel, then windows; 3 = global-index kernel
-                                       // (kernels_mapray.hip), then windows; 4 = whole-fan, global-index, windows; 5 = as 0, explicitly
+    int mu_mode;                       // 0 = event-walk kernel (kernels_mapev.hip; the global-index kernel of round 2, kernels_mapray.hip, where
+                                       // that one is not available: more than 1536 beams), then 128x128 windows for what it gave back;
+                                       // 1 = 128x128 windows only; 3 = global-index kernel, then windows; 5 = event-walk kernel, then windows
     uint32_t* ndt_occ; double* ndt_aux; // NDT stage: the matcher's staged field per particle, its grid optimum (kernels_match.hip)
     int ndt_refine;                    // rbpf_config.ndt_refine: NDT stage of matchScanCustom.m:32-50 (0 off, 1 reference rule, 2 always)
     int32_t* dup_of; int dups_valid;    // representative of each particle's group of exact duplicates since the last resample (kernels_resample.hip); valid until the next proposal
@@ -158,8 +156,6 @@ void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t
 void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s);   // bytes rounded up to 16
 void launch_ingest2(const int32_t* mapped_a, int32_t* d_a, const int32_t* mapped_b, int32_t* d_b, int n, hipStream_t s);
 void launch_readback(void* mapped_dst, const double* d_nan_elem, const int32_t* d_did, const int32_t* d_idx, int n, hipStream_t s);
-bool map_update_fan_available(const DevView& v);
-void launch_map_update_fan(const DevView& v, hipStream_t s);
 bool map_update_ray_available(const DevView& v);
 void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s);
 bool map_update_ev_available(const DevView& v);

@@ -25,6 +25,14 @@ class CarmenLog:
     order: np.ndarray         # [n_scans + n_odom] records in file order: >= 0 scan index, < 0 -(odom index) - 1
 
 
+def _open_text(path: str):
+    """A log as text, gzip-compressed or plain."""
+    if path.endswith(".gz"):
+        import gzip
+        return gzip.open(path, "rt")
+    return open(path)
+
+
 def load_carmen(path: str, time_scale: int = 10) -> CarmenLog:
     """`time_scale` = 10 reproduces the Intel adapters' `int(10*t)*10`; the Freiburg-style adapters use 1000."""
     scans: List[List[float]] = []
@@ -33,7 +41,7 @@ def load_carmen(path: str, time_scale: int = 10) -> CarmenLog:
     ot: List[int] = []
     order: List[int] = []
     n_beams = None
-    with open(path) as f:
+    with _open_text(path) as f:
         for line in f:
             tok = line.split()
             if not tok:
