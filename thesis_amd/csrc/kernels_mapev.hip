@@ -47,7 +47,7 @@ __host__ __device__ inline int ev_al16(int x) { return (x + 15) & ~15; }
 
 struct EvGeom {
     int fanw, bpad, ncell, T, logT, E;
-    int o_mini, o_fs, o_end, o_nE, o_perm, o_info, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_evl, o_cnt;
+    int o_mini, o_fs, o_end, o_nE, o_perm, o_kl, o_info, o_ux, o_uy, o_gxb, o_gyb, o_gym, o_evl, o_cnt;
     int p_keys, p_cnta, p_offs, p_oldv, p_rlist, p_evl, p_ic, p_bytes;              // the window's LDS after the write-back
     int bytes;
     bool ok;
@@ -62,6 +62,7 @@ __host__ __device__ inline EvGeom ev_geom(int B, int reach) {
     g.o_end = o;   o += ev_al16(g.bpad * 4);
     g.o_nE = o;    o += ev_al16(g.bpad * 2);
     g.o_perm = o;  o += ev_al16(g.bpad * 2);
+    g.o_kl = o;    o += ev_al16(g.bpad * 2);
     g.o_info = o;  o += ev_al16(g.bpad);
     g.o_ux = o;    o += ev_al16(g.fanw * 2);
     g.o_uy = o;    o += ev_al16(g.fanw * 2);
@@ -142,6 +143,23 @@ __device__ __forceinline__ uint32_t ev_min4(uint32_t n7, uint32_t satb, uint32_t
     return (satb & gem) | (n7 & ~gem);
 }
 
+// One word of four cells through the write-back's arithmetic (gridmap.py:97-101, n times, byte-wise): returns the new word;
+// `touched` / `occ` get the word's four bits (field not zero / cell > threshold).
+struct EvWb { uint32_t kb1, oadd, satb, sadd; int eabs; };
+__device__ __forceinline__ uint32_t ev_wb_word(const EvWb& k, uint32_t pre, uint32_t n7, uint32_t& touched4, uint32_t& occ4) {
+    const uint32_t Ob = (pre ^ 0x80808080u) - k.kb1;                          // cells biased to [0, vmax - vmin]
+    const uint32_t m = ev_min4(n7, k.satb, k.sadd);                           // min(n, sat)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint32_t dec = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, m) * (us2)(unsigned short)k.eabs);   // byte-wise: sat * |emp| < 128, no carries
+    const uint32_t T1 = (Ob | 0x80808080u) - dec;
+    const uint32_t pos = T1 & 0x80808080u;                                    // O - dec >= 0
+    const uint32_t R = T1 & 0x7F7F7F7Fu & (pos | (pos - (pos >> 7)));
+    const uint32_t nz = (n7 + 0x7F7F7F7Fu) & 0x80808080u;                     // fields that are not zero
+    touched4 = __builtin_amdgcn_udot4(nz >> 7, 0x08040201u, 0u, false);
+    occ4 = __builtin_amdgcn_udot4(((R + k.oadd) & 0x80808080u) >> 7, 0x08040201u, 0u, false);   // cell > thr
+    return (R + k.kb1) ^ 0x80808080u;
+}
+
 // open addressing, linear probing, keys never ~0
 __device__ __forceinline__ int ev_hash_insert(uint32_t* keys, int T, int logT, uint32_t sc) {
     uint32_t h = (sc * 2654435761u) >> (32 - logT);
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     uint16_t* const r_nE = reinterpret_cast<uint16_t*>(smem + G.o_nE);     // [B] steps the walk takes
     uint16_t* const perm = reinterpret_cast<uint16_t*>(smem + G.o_perm);   // rays ordered by falling count of whole chunks
     uint8_t*  const r_info = smem + G.o_info;                              // [B]
+    uint16_t* const r_kl = reinterpret_cast<uint16_t*>(smem + G.o_kl);     // [B] first whole chunk of the ray's share of the level walk | chunks << 8 (a strip: those inside it)
     uint16_t* const ux = reinterpret_cast<uint16_t*>(smem + G.o_ux);       // U of global column fxl + i
     uint16_t* const uy = reinterpret_cast<uint16_t*>(smem + G.o_uy);
     uint8_t*  const gxb = smem + G.o_gxb;                                  // G of global column fxl + i (0 / 1)
@@ -326,6 +345,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             r_end[b] = (int32_t)(((uint32_t)ddx & 0xFFFFu) | ((uint32_t)ddy << 16));
             r_nE[b] = (uint16_t)nE;
             r_info[b] = (uint8_t)info;
+            r_kl[b] = (uint16_t)(1 | ((nE > NEAR_R ? (nE - NEAR_R) / LCH : 0) << 8));
         }
         const int ws = wave_sum((int)my_cells);
         fx0 = wave_min(fx0); fx1 = wave_max(fx1); fy0 = wave_min(fy0); fy1 = wave_max(fy1);
@@ -463,7 +483,8 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     const int sat = (v.cc.vmax - v.cc.vmin + (-v.cc.emp) - 1) / (-v.cc.emp);        // passes that saturate any cell: 20
     const uint32_t satb = (uint32_t)sat * 0x01010101u, sadd = (128u - (uint32_t)sat) * 0x01010101u;
     const int cnt_lds = ev_lds_addr(cnt), mini_lds = ev_lds_addr(mini);
-    const int nlev = UNI(s_nlev);
+    // a thin fan: fewer ray cells than two fifths of the fan's box (181 beams on a 0.025 m grid: a seventh)
+    const bool sparse = (long long)UNI((int)s_cells) * 5 < 2LL * (long long)(S_hi - S_lo + 1) * (long long)(T_hi - T_lo + 1);
     // a lane's steps that met a flagged cell (bit 16 + u of m = step j0 + u): into the event list
     auto log_events = [&](uint32_t m, int b, int j0, int ev_lo, int ev_hi, int gx_base, bool filter) {
         while (m) {
@@ -571,23 +592,128 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             const int rx0 = x0 - gx_base, ry0 = y0 - gy_base;
             const int base0 = rx0 * stride + ry0 + cnt_lds;
             const int win_lo = cnt_lds, win_n = rows_w * stride;
-            const int nitems = UNI(s_lp[nlev + 1]);                               // (levels above nlev have no waves: s_lp stays flat)
+            // one predicated chunk of ray b (steps j0 .. j0 + 15, those in [jlo, jhi] and inside the window count): the tail of a
+            // ray, or - in a strip - a chunk the strip's edge cuts.  Branch-free: a dead step adds nothing to a word of the lane's own.
+            auto walk_pred = [&](int b, int j0, int jlo, int jhi) {
+                const uint32_t fs = r_fs[b];
+                const RayDir d = ray_dir(b);
+                const int sxs = d.sx * stride;
+                const int cj = d.steep ? d.sy : sxs, cm = d.steep ? sxs : d.sy;
+                const unsigned long long pr64 = (unsigned long long)fs * (unsigned)j0 + 0x80000000ull;
+                uint32_t acc = (uint32_t)pr64, m = 0, inm = 0;
+                int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
+                const int d0 = cj, d1 = cj + cm;
+                uint32_t ret[LCH]; int sh[LCH];
+#pragma unroll
+                for (int u = 0; u < LCH; ++u) {
+                    const bool in = j0 + u >= jlo && j0 + u <= jhi && (unsigned)(c - win_lo) < (unsigned)win_n;
+                    sh[u] = c << 3;
+                    ret[u] = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << (sh[u] & 31));
+                    inm |= in ? 1u << u : 0u;
+                    const uint32_t nacc = acc + fs;
+                    c += nacc < acc ? d1 : d0;
+                    acc = nacc;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit((inm >> u) & (ret[u] >> (sh[u] & 31)), m, 1);
+                if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
+            };
+            if (whole) {
+                // the tail of every ray with more than NEAR_R steps (its whole chunks follow, level by level)
+                for (int b = tid; b < v.B; b += EB) {
+                    const int nE = (int)r_nE[b];
+                    if (nE <= NEAR_R) continue;
+                    const int j0 = NEAR_R + ((nE - NEAR_R) / LCH) * LCH;            // first step after the whole chunks
+                    if (j0 < nE) walk_pred(b, j0, j0, nE - 1);
+                }
+            } else {
+                // A strip holds a part of every ray: the steps NEAR_R .. nE - 1 whose row lies in the strip are a run
+                // [lo, hi] (rows never turn back along a ray).  The whole chunks inside the run are the ray's share of the
+                // strip's level walk (relative levels: rays ordered by how many such chunks they have); the one or two chunks
+                // that the strip's edge or the ray's end cuts are walked here, predicated.
+                if (tid <= MAXLEV) s_lcnt[tid] = 0;
+                BAR_LDS();
+                auto first_j = [&](uint32_t fs, int mval) -> int {               // first step with minor(j) >= mval (mval >= 1)
+                    if (fs == 0u) return 1 << 20;
+                    const double jd = ((double)mval * 4294967296.0 - 2147483648.0) / (double)fs;
+                    if (jd > 4000.0) return 1 << 20;
+                    int j = (int)jd;
+                    while (ev_minor(fs, j) < mval) ++j;
+                    while (j > 0 && ev_minor(fs, j - 1) >= mval) --j;
+                    return j;
+                };
+                for (int b = tid; b < v.B; b += EB) {
+                    const int nE = (int)r_nE[b];
+                    int ka = 1, len = 0;
+                    if (nE > NEAR_R) {
+                        const uint32_t fs = r_fs[b];
+                        const RayDir d = ray_dir(b);
+                        int lo = NEAR_R, hi = nE - 1;
+                        if (!d.steep) {                                            // row = rx0 + sx * j
+                            if (d.sx > 0) { lo = max(lo, -rx0); hi = min(hi, rows_w - 1 - rx0); }
+                            else { lo = max(lo, rx0 - (rows_w - 1)); hi = min(hi, rx0); }
+                        } else {                                                   // row = rx0 + sx * minor(j), minor never decreases
+                            const int mlo = d.sx > 0 ? -rx0 : rx0 - (rows_w - 1), mhi = d.sx > 0 ? rows_w - 1 - rx0 : rx0;
+                            if (mhi < 0) hi = -1;
+                            else {
+                                if (mlo > 0) lo = max(lo, first_j(fs, mlo));
+                                hi = min(hi, first_j(fs, mhi + 1) - 1);
+                            }
+                        }
+                        if (lo <= hi) {
+                            const int nfull = (nE - NEAR_R) / LCH;
+                            const int kf = (lo - NEAR_R) / LCH + 1, kl = (hi - NEAR_R) / LCH + 1;   // the chunks that hold the first / the last step
+                            const int a = lo == NEAR_R + (kf - 1) * LCH ? kf : kf + 1;             // first chunk that lies inside as a whole
+                            const int e = min(hi == NEAR_R + kl * LCH - 1 ? kl : kl - 1, nfull);   // last one
+                            if (e >= a) { ka = a; len = e - a + 1; }
+                            if (kf < a || kf > e) walk_pred(b, NEAR_R + (kf - 1) * LCH, lo, hi);
+                            if (kl != kf && (kl < a || kl > e)) walk_pred(b, NEAR_R + (kl - 1) * LCH, lo, hi);
+                        }
+                    }
+                    r_kl[b] = (uint16_t)(ka | (len << 8));
+                    if (len) atomicAdd(&s_lcnt[min(len, MAXLEV)], 1);
+                }
+                BAR_LDS();
+                if (wave == 0) {   // relative levels: N_k = rays with at least k whole chunks inside the strip
+                    const int k = lane;
+                    const int ck = k >= 1 ? s_lcnt[k] : 0;
+                    int suf = ck;
+                    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(suf, o, 64); if (lane + o < 64) suf += t; }
+                    const int nwk = k >= 1 ? (suf + 63) >> 6 : 0;
+                    int pre = nwk;
+                    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
+                    const unsigned long long live = __ballot(k >= 1 && suf > 0);
+                    if (k >= 1) { s_lfill[k] = suf - ck; s_nk[k] = suf; s_lp[k] = pre - nwk; }
+                    if (k == 63) s_lp[64] = pre;
+                    if (k == 0) { s_nlev = live ? 63 - __clzll((long long)live) : 0; s_nk[MAXLEV + 1] = 0; }
+                }
+                BAR_LDS();
+                for (int b = tid; b < v.B; b += EB) {
+                    const int len = (int)r_kl[b] >> 8;
+                    if (len) perm[atomicAdd(&s_lfill[min(len, MAXLEV)], 1)] = (uint16_t)b;
+                }
+                BAR_LDS();
+            }
+            // ---- the level walk: every lane runs all 16 steps of a whole chunk (inside the window as a whole) ----
+            const int nlev_w = UNI(s_nlev);
+            const int nitems = UNI(s_lp[nlev_w + 1]);                             // (levels above nlev have no waves: s_lp stays flat)
             // the next item's ray is fetched while this one's adds are in flight
             int k = 1, kn = 1;
             int lp_c = UNI(s_lp[1]), lp_n = UNI(s_lp[2]), nk_c = UNI(s_nk[1]);    // first item of the level, of the next level; rays of the level
-            int nb = -1; uint32_t nfs = 0; int32_t nend = 0;
+            int nb = -1, nka = 1; uint32_t nfs = 0; int32_t nend = 0;
             auto fetch_item = [&](int q) {
                 nb = -1;
                 if (q >= nitems) return;
-                while (kn < nlev && q >= lp_n) { ++kn; lp_c = lp_n; lp_n = UNI(s_lp[kn + 1]); nk_c = UNI(s_nk[kn]); }
+                while (kn < nlev_w && q >= lp_n) { ++kn; lp_c = lp_n; lp_n = UNI(s_lp[kn + 1]); nk_c = UNI(s_nk[kn]); }
                 const int nwk = (nk_c + 63) >> 6, wslot = q - lp_c;
                 const int ii = lane * nwk + wslot;
-                if (ii < nk_c) { nb = perm[ii]; nfs = r_fs[nb]; nend = r_end[nb]; }
+                if (ii < nk_c) { nb = perm[ii]; nfs = r_fs[nb]; nend = r_end[nb]; nka = (int)r_kl[nb] & 0xFF; }
             };
             fetch_item(wave);
             for (int q = wave; q < nitems; q += EB / 64) {
                 const int b = nb; const uint32_t fs = nfs; const int32_t re = nend;
-                k = kn;
+                k = kn + nka - 1;                                                 // the ray's chunk at this relative level
                 if (b < 0) { fetch_item(q + EB / 64); continue; }
                 const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
                 const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
@@ -599,69 +725,19 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                 int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
                 const int d0 = cj, d1 = cj + cm;
                 uint32_t ret[LCH]; int sh[LCH];
-                if (whole) {
 #pragma unroll
-                    for (int u = 0; u < LCH; ++u) {
-                        sh[u] = c << 3;
-                        ret[u] = ev_lds_add_rtn(c & ~3, 2u << (sh[u] & 31));
-                        const uint32_t nacc = acc + fs;
-                        c += nacc < acc ? d1 : d0;
-                        acc = nacc;
-                    }
-                    fetch_item(q + EB / 64);
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): one wait, then the sixteen answers
-#pragma unroll
-                    for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit(ret[u] >> (sh[u] & 31), m, 1);
-                } else {
-                    uint32_t inm = 0;
-#pragma unroll
-                    for (int u = 0; u < LCH; ++u) {
-                        const bool in = (unsigned)(c - win_lo) < (unsigned)win_n;       // the columns always fit: a test of the row
-                        sh[u] = c << 3;
-                        ret[u] = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << (sh[u] & 31));
-                        inm |= in ? 1u << u : 0u;
-                        const uint32_t nacc = acc + fs;
-                        c += nacc < acc ? d1 : d0;
-                        acc = nacc;
-                    }
-                    fetch_item(q + EB / 64);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit((inm >> u) & (ret[u] >> (sh[u] & 31)), m, 1);
-                }
-                if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
-            }
-            // the partial chunk at the end of every ray with more than NEAR_R steps
-            for (int b = tid; b < v.B; b += EB) {
-                const int nE = (int)r_nE[b];
-                if (nE <= NEAR_R) continue;
-                const int j0 = NEAR_R + ((nE - NEAR_R) / LCH) * LCH;                // first step after the whole chunks
-                const int left = nE - j0;
-                if (left <= 0) continue;
-                const uint32_t fs = r_fs[b];
-                const RayDir d = ray_dir(b);
-                const int sxs = d.sx * stride;
-                const int cj = d.steep ? d.sy : sxs, cm = d.steep ? sxs : d.sy;
-                const unsigned long long pr64 = (unsigned long long)fs * (unsigned)j0 + 0x80000000ull;
-                uint32_t acc = (uint32_t)pr64, m = 0, inm = 0;
-                int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
-                const int d0 = cj, d1 = cj + cm;
-                uint32_t ret[LCH - 1]; int sh[LCH - 1];
-#pragma unroll
-                for (int u = 0; u < LCH - 1; ++u) {                                // branch-free: a dead step adds nothing to a word of the lane's own
-                    const bool in = u < left && (whole || (unsigned)(c - win_lo) < (unsigned)win_n);
+                for (int u = 0; u < LCH; ++u) {
                     sh[u] = c << 3;
-                    ret[u] = ev_lds_add_rtn(in ? c & ~3 : win_lo + 4 * lane, (in ? 2u : 0u) << (sh[u] & 31));
-                    inm |= in ? 1u << u : 0u;
+                    ret[u] = ev_lds_add_rtn(c & ~3, 2u << (sh[u] & 31));
                     const uint32_t nacc = acc + fs;
                     c += nacc < acc ? d1 : d0;
                     acc = nacc;
                 }
+                fetch_item(q + EB / 64);
                 __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): one wait, then the sixteen answers
 #pragma unroll
-                for (int u = 0; u < LCH - 1; ++u) m = __builtin_amdgcn_alignbit((inm >> u) & (ret[u] >> (sh[u] & 31)), m, 1);
-                m >>= 1;                                                          // (15 steps: bit 16 + u as in a whole chunk)
+                for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit(ret[u] >> (sh[u] & 31), m, 1);
                 if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
             }
         }
@@ -682,6 +758,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         {
             int my_written = 0;
             const int eabs = -v.cc.emp;
+            const EvWb wbk = {(uint32_t)(128 + v.cc.vmin) * 0x01010101u, (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u, satb, sadd, -v.cc.emp};
             const uint32_t kb1 = (uint32_t)(128 + v.cc.vmin) * 0x01010101u;             // byte-wise: (cell ^ 0x80) - kb1 = cell - vmin
             const uint32_t oadd = (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u; // bit 7 of (R + oadd) = cell > thr
             for (int a = S0 / v.dim; a <= S1 / v.dim; ++a)
@@ -754,6 +831,39 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                     } else {
 #pragma unroll
                         for (int w = 0; w < 8; ++w) pre[w] = w < nw ? g_ptr[w] : 0u;
+                    }
+                    if (sparse) {   // a thin fan (few beams on a fine grid): a group holds one or two touched words - the arithmetic and
+                                    // the stores are theirs alone; the other words only give their occupancy bits (the group's 32 bytes are
+                                    // one memory sector: read whole, written by the word)
+                        uint32_t nzm = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) nzm |= n[w] ? 1u << w : 0u;
+                        if (__popc(nzm) <= 3) {
+                            uint32_t occ = 0, touched = 0;
+#pragma unroll
+                            for (int w = 0; w < 8; ++w)                                       // cell > thr of the cells as they are
+                                occ |= __builtin_amdgcn_udot4(((((pre[w] ^ 0x80808080u) - wbk.kb1) + wbk.oadd) & 0x80808080u) >> 7, 0x08040201u, 0u, false) << (4 * w);
+                            if (nw < 8) occ &= (1u << (4 * nw)) - 1u;
+                            uint32_t mm = nzm;
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) {
+                                const int wq = mm ? __ffs((int)mm) - 1 : -1;
+                                mm &= mm - 1;
+                                if (wq < 0) continue;
+                                uint32_t pw = 0, nv = 0;
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) { pw = w == wq ? pre[w] : pw; nv = w == wq ? n[w] : nv; }
+                                uint32_t t4, o4;
+                                g_ptr[wq] = ev_wb_word(wbk, pw, nv, t4, o4);
+                                touched |= t4 << (4 * wq);
+                                occ = (occ & ~(0xFu << (4 * wq))) | (o4 << (4 * wq));
+                            }
+                            v.occ[((size_t)tile * v.dim + row_t) * v.ow + gt] = occ;
+                            my_written += __popc(touched);
+                            by0 = min(by0, col_t + __ffs(touched) - 1); by1 = max(by1, col_t + 31 - __clz(touched));
+                            bx0 = min(bx0, row_t); bx1 = max(bx1, row_t);
+                            continue;
+                        }
                     }
                     uint32_t occ = 0, touched = 0, out[8];
 #pragma unroll
