@@ -532,7 +532,8 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         //      count of one, so a flagged field is never zero (the write-back takes "touched" from the field) ----
 #pragma unroll
         for (int i = 0; i < NPAIR; ++i) {
-            const uint32_t sc = my_sc[i];
+            uint32_t sc = my_sc[i];
+            asm volatile("" : "+v"(sc));                                         // (the cell's sources are worked out here, strip by strip: hoisted out of the strips' loop they were 24 registers spilled to scratch)
             if (sc == 0xFFFFFFFFu) continue;
             FCell f;
             cell_sources(sc, f);
