@@ -113,7 +113,7 @@ typedef struct rbpf_counters {
                                      the whole ray fan fits one window)                                            */
     uint64_t fallback_geometry;   /* particles handed to the 128x128-window kernel: fan / index-map form / LDS rows  */
     uint64_t fallback_bound;      /* ... the 8-bit hit fields could overflow (slope-bucket bound)                   */
-    uint64_t fallback_tables;     /* ... event tables full (global-index and whole-fan kernels)                     */
+    uint64_t fallback_tables;     /* ... event tables full (global-index kernel)                                    */
     uint64_t map_events;          /* event-walk kernel: passes over cells that also got an occupied / nearby hit in
                                      the same scan, found by the walk's returning adds, summed over particles       */
     uint64_t map_event_overflows; /* ... particles whose list of such passes was full (every flagged cell of theirs

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,11 +15,14 @@ namespace rbpf {
 // launcher's own table of what it has set so far (one entry per device).
 static const int MAX_DEVICES = 16;
 inline void ensure_dynamic_lds(const void* fn, size_t bytes, size_t* set) {
+    static std::mutex mu;                              // handles on several host threads share the launchers' tables
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
     const bool tracked = dev >= 0 && dev < MAX_DEVICES;
     if (tracked && bytes <= set[dev]) return;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc != hipSuccess) { (void)hipGetLastError(); return; }   // not recorded as set: the launch that follows reports the error
     if (tracked) set[dev] = bytes;
 }
 

@@ -96,6 +96,18 @@ class _Session:
         self.pf: Optional[ParticleFilter] = None
         self.round_key = None
         self.round_seen = set()
+        self._cache = {}                                 # poses / weights / covs of the whole population, read back once per round
+
+    def state(self, what: str) -> np.ndarray:
+        """engine.poses() / weights() / covs(), read back once and kept until the next call that changes them: a list
+        comprehension over P Robots costs one device read-back, not P."""
+        if what not in self._cache:
+            e = self.filter().engine
+            self._cache[what] = {"poses": e.poses, "weights": e.weights, "covs": e.covs}[what]()
+        return self._cache[what]
+
+    def invalidate(self):
+        self._cache = {}
 
     def filter(self) -> ParticleFilter:
         if self.pf is None:
@@ -139,7 +151,10 @@ class HybridMap(_MapView):
     def __init__(self, session: _Session, index: int):
         self._s, self._i = session, index
         self._cell_size = session.cell_size
-        self._size = 40.0
+
+    @property
+    def _size(self) -> float:                         # hybridmap.py:68 map_len_m, from the engine's configuration
+        return float(self._s.filter().engine.cfg.tile_len_m)
 
     @property
     def _pf(self):                                    # the base class's methods go through the live filter
@@ -200,6 +215,8 @@ class Robot:
             prev = _session
             _session = _Session(*(("velocity", 0.05, 1081, 42, {}) if prev is None else
                                   (prev.motion_model, prev.cell_size, prev.n_beams, prev.seed, prev.options)))
+            if prev is not None:
+                prev.close()                              # the population before this one is done with: its engine and tile pool go now
         self._s = _session
         self._i = len(self._s.robots)
         self._s.robots.append(self)
@@ -207,11 +224,11 @@ class Robot:
 
     # -- reads (robot.py:30-43) --------------------------------------------------------------------------------
     def get_latest_pose(self) -> Pose:
-        p = self._s.filter().engine.poses()[self._i]
+        p = self._s.state("poses")[self._i]
         return Pose(float(p[0]), float(p[1]), float(p[2]))
 
     def weight(self):
-        return [float(self._s.filter().engine.weights()[self._i])]
+        return [float(self._s.state("weights")[self._i])]
 
     @property
     def _weight(self):                                # main.py:47,78 read and append to it
@@ -219,7 +236,7 @@ class Robot:
 
     @property
     def _cov(self):
-        return self._s.filter().engine.covs()[self._i]
+        return self._s.state("covs")[self._i]
 
     def x(self):
         return [p[0] for p in self._s.filter().trajectory(self._i)]
@@ -235,6 +252,7 @@ class Robot:
         pf = self._s.filter()
         if self._s.first_of_round(self, ("imu", id(reading))):
             pf.imu_update(np.asarray(reading.get_data(), dtype=np.float64), float(reading.dt()))
+            self._s.invalidate()
         return self.get_latest_pose()
 
     def map_update(self, scan, last_scan, adj: bool):  # robot.py:59-115, main.py:157,159
@@ -246,6 +264,7 @@ class Robot:
                 ls = np.stack([np.asarray(last_scan.x(), dtype=np.float64), np.asarray(last_scan.y(), dtype=np.float64)], axis=1)
             pf.engine.scan_update(adj=bool(adj), last_scan_xy=ls)
             pf._record(None)
+            self._s.invalidate()
 
     def copy(self):
         """robot.py:141-149: a detached snapshot (histories, covariance, weight, map) - the copies resampling needs are
@@ -270,4 +289,5 @@ def resample(particles: List[Robot], u: Optional[float] = None) -> List[Robot]:
     s = particles[0]._s
     s.round_key = None
     s.filter().resample(float(np.random.random()) if u is None else float(u))
+    s.invalidate()
     return particles
