@@ -85,7 +85,7 @@ __host__ __device__ inline int match_crs_words(int N) { return ((N / M_COARSE) +
 static size_t match_lds_base(int N, int B) {
     size_t words = (size_t)N * (N / 32);
     size_t dec = (size_t)(((B + 3) / 4 + 7) & ~3) + (size_t)(((B + 7) / 8 + 7) & ~3);
-    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + dec * 8 + 256;
+    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + 16 + dec * 8 + 256;
 }
 // The score table holds the coarse candidates of as many rotations as fit when TWO workgroups share a CU's 160 KB (the
 // kernel's instruction stream keeps one workgroup's eight waves busy half of the time), at least one rotation's
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     s.dil = s.occ + (size_t)N * W;
     s.crs = s.dil + (size_t)N * W;
     const int cap4 = ((a.cap_sel + 3) / 4 + 7) & ~3, cap8 = ((a.cap_sel + 7) / 8 + 7) & ~3;
-    s.fx4 = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N)); s.fy4 = s.fx4 + cap4;
+    s.fx4 = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N) + 4); s.fy4 = s.fx4 + cap4;   // (+4: a zero word after the coarse map)
     s.cx8 = s.fy4 + cap4; s.cy8 = s.cx8 + cap8;
     s.sc = reinterpret_cast<int*>(s.cy8 + cap8);
     __shared__ double s_g[3], s_rng[2];
@@ -388,6 +388,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         }
         s.crs[q] = out;
     }
+    if (tid == 0) s.crs[(N / M_COARSE) * match_crs_words(N)] = 0;       // looked up in place of cells outside the region
     __syncthreads();
 
     const int nb = s_nb;
@@ -399,91 +400,106 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     const int kty = (int)ceil(ryc / M_COARSE) - 1;
     const int ntx = 2 * max(ktx, 0) + 1, nty = 2 * max(kty, 0) + 1;
     const int nr = 2 * a.n_coarse_rot + 1;
-    const int per_rot = ntx * nty;
-    // the score table holds the candidates of RG rotations: the coarse level runs in groups of rotations (the table of all
-    // 57 x 81 candidates would keep a second workgroup off the CU)
-    const int RG = max(1, min(nr, a.sc_cap / per_rot));
+    // The score table holds 16-bit sums, two per word, laid out as the byte lanes of the accumulators fall: a pass of 8 y
+    // translations is four words (y 0|2, 1|3, 4|6, 5|7), so an item adds four candidates' sums with two atomics and no
+    // extraction.  It holds the candidates of RG rotations; the coarse level runs in equal groups of rotations when the
+    // table of all of them would keep a second workgroup off the CU.
+    const int NP = (nty + 7) >> 3;                                       // passes of 8 y translations
+    const int rot_words = ntx * NP * 4;
+    const int RGmax = max(1, min(nr, a.sc_cap / rot_words));
+    const int n_groups = (nr + RGmax - 1) / RGmax;
+    const int RG = (nr + n_groups - 1) / n_groups;
 
     MSTAMP(2);
     // Neighbouring translation candidates along y are consecutive bits of one mask row, so one LDS read scores a whole
-    // row of them: a work item is (rotation, x translation); its per-candidate sums are byte lanes of two registers.
+    // row of them: a work item is (rotation, beam slice); its per-candidate sums are byte lanes of two registers.
     const int n4 = ((nb + 3) / 4 + 3) & ~3;                                      // padded with far-away beams
     const float gthf = (float)remainder(gth, 6.283185307179586);
     const int CW = match_crs_words(N);
     const int NC4 = N / M_COARSE;
+    uint32_t* const sc2 = reinterpret_cast<uint32_t*>(s.sc);
     // ---- coarse level -------------------------------------------------------------------------------------------
     // work item = (rotation, beam slice): a beam is rotated once and looked up for every x translation (a shift by whole
     // coarse cells) and, through the byte lanes, for 8 y translations per LDS read; slices add their sums with atomics
     int g_best = INT_MIN, g_key = INT_MAX;                               // best score so far and its tie-break key (uniform)
     for (int r0 = 0; r0 < nr; r0 += RG) {
-    const int nrg = min(RG, nr - r0), n_coarse = nrg * per_rot;
-    for (int i = tid; i < n_coarse; i += MBLOCK) s.sc[i] = 0;           // candidate sums are accumulated with atomics
+    const int nrg = min(RG, nr - r0), n_words = nrg * rot_words;
+    for (int i = tid; i < n_words; i += MBLOCK) sc2[i] = 0;             // candidate sums are accumulated with atomics
     if (tid == 0) { s_best = INT_MIN; s_bestc = INT_MAX; }
     __syncthreads();
     {
         const int MAXTX = 7;
         const int NSC = max(1, MBLOCK / nrg), nb8 = (nb + 7) / 8, per = (nb8 + NSC - 1) / NSC;   // beams per slice
+        const int ZERO = NC4 * CW;                                       // a word of the coarse map that is always 0
         for (int item = tid; item < nrg * NSC; item += MBLOCK) {
             const int irl = item / NSC, ir = r0 + irl, sl = item % NSC;
             float sn, cs;
             __sincosf(gthf + (float)((double)(ir - a.n_coarse_rot) * M_COARSE * a.d0), &sn, &cs);
             const int g_lo = sl * per, g_hi = min(nb8, g_lo + per);
-            for (int g0 = 0; g0 < nty; g0 += 8)                         // up to 8 y translations per pass
+            for (int pass = 0; pass < NP; ++pass)                       // up to 8 y translations per pass
             for (int t0 = 0; t0 < ntx; t0 += MAXTX)                     // up to MAXTX x translations per pass
             for (int gg = g_lo; gg < g_hi; gg += 240) {                 // byte-lane sums stay below 256
-                const float ty0 = fy + (float)((g0 - max(kty, 0)) * M_COARSE);
+                const float ty0 = fy + (float)((pass * 8 - max(kty, 0)) * M_COARSE);
                 uint32_t accA[MAXTX], accB[MAXTX];
 #pragma unroll
                 for (int t = 0; t < MAXTX; ++t) { accA[t] = 0; accB[t] = 0; }
                 const int ge = min(g_hi, gg + 240);
                 for (int g = gg; g < ge; ++g) {
                     const float bxs = s.cx8[g], bys = s.cy8[g];
-                    {
-                        const int u0 = (int)floorf(cs * bxs - sn * bys + fx) + (t0 - max(ktx, 0)) * M_COARSE;
-                        const int cw0 = (int)floorf(sn * bxs + cs * bys + ty0) >> 2;         // candidate j looks at coarse column cw0 + j
-                        const bool col_ok = cw0 >= 0 && cw0 + 7 < NC4;
-                        const int sh = cw0 & 15, wi = cw0 >> 4;                              // one overlapping word holds all 8
+                    const int cu0 = ((int)floorf(cs * bxs - sn * bys + fx) + (t0 - max(ktx, 0)) * M_COARSE) >> 2;   // x translation t looks at coarse row cu0 + t
+                    const int cw0 = (int)floorf(sn * bxs + cs * bys + ty0) >> 2;             // candidate j looks at coarse column cw0 + j
+                    const bool col_ok = cw0 >= 0 && cw0 + 7 < NC4;
+                    const uint32_t sh = (uint32_t)(cw0 & 15);                                // one overlapping word holds all 8
+                    const int i00 = cu0 * CW + (cw0 >> 4);
 #pragma unroll
-                        for (int t = 0; t < MAXTX; ++t) {
-                            const int u = u0 + t * M_COARSE;
-                            const bool in = col_ok && t0 + t < ntx && (unsigned)u < (unsigned)N;
-                            const int i0 = in ? (u >> 2) * CW + wi : 0;
-                            const uint32_t bits = in ? (s.crs[i0] >> sh) & 0xFFu : 0u;
-                            accA[t] += ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
-                            accB[t] += ((bits >> 4) * 0x00204081u) & 0x01010101u;
-                        }
+                    for (int t = 0; t < MAXTX; ++t) {
+                        const bool in = col_ok && (unsigned)(cu0 + t) < (unsigned)NC4;
+                        const uint32_t word = s.crs[in ? i00 + t * CW : ZERO];
+                        accA[t] += (__builtin_amdgcn_ubfe(word, sh, 4u) * 0x00204081u) & 0x01010101u;
+                        accB[t] += (__builtin_amdgcn_ubfe(word, sh + 4u, 4u) * 0x00204081u) & 0x01010101u;
                     }
                 }
 #pragma unroll
                 for (int t = 0; t < MAXTX; ++t) {
                     if (t0 + t >= ntx) continue;
-                    int* dst = s.sc + (irl * ntx + t0 + t) * nty + g0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int val = (int)(((j < 4 ? accA[t] : accB[t]) >> (8 * (j & 3))) & 0xFFu);
-                        if (g0 + j < nty && val) atomicAdd(&dst[j], val);
-                    }
+                    uint32_t* dst = sc2 + ((irl * ntx + t0 + t) * NP + pass) * 4;
+                    const uint32_t A = accA[t], B = accB[t];
+                    if (A) { atomicAdd(dst + 0, A & 0x00FF00FFu); atomicAdd(dst + 1, (A >> 8) & 0x00FF00FFu); }
+                    if (B) { atomicAdd(dst + 2, B & 0x00FF00FFu); atomicAdd(dst + 3, (B >> 8) & 0x00FF00FFu); }
                 }
             }
         }
     }
     __syncthreads();
+    // word k of a pass holds y translations j0 = 4 (k >> 1) + (k & 1) (low half) and j0 + 2 (high half)
     {
         int mx = INT_MIN;
-        for (int cnd = tid; cnd < n_coarse; cnd += MBLOCK) mx = max(mx, s.sc[cnd]);
+        for (int w = tid; w < n_words; w += MBLOCK) {
+            const int k = w & 3, iy0 = ((w >> 2) % NP) * 8 + 4 * (k >> 1) + (k & 1);
+            const uint32_t val = sc2[w];
+            if (iy0 < nty) mx = max(mx, (int)(val & 0xFFFFu));
+            if (iy0 + 2 < nty) mx = max(mx, (int)(val >> 16));
+        }
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
         if ((tid & 63) == 0) atomicMax(&s_best, mx);
     }
     __syncthreads();
     const int best_group = s_best;
-    for (int cl = tid; cl < n_coarse; cl += MBLOCK) {
-        if (s.sc[cl] == best_group) {
-            // ties: the candidate closest to the guess, then the lowest index (deterministic)
-            const int cnd = r0 * per_rot + cl;                                   // index over all rotations
-            const int ir = cnd / (ntx * nty), it = cnd % (ntx * nty);
-            int dr = ir - a.n_coarse_rot, dx = it / nty - max(ktx, 0), dy = it % nty - max(kty, 0);
-            int key = ((dr * dr + dx * dx + dy * dy) << 16) | cnd;
-            atomicMin(&s_bestc, key);
+    for (int w = tid; w < n_words; w += MBLOCK) {
+        const int k = w & 3, iy0 = ((w >> 2) % NP) * 8 + 4 * (k >> 1) + (k & 1);
+        const uint32_t val = sc2[w];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int iy = iy0 + 2 * hf, sco = hf ? (int)(val >> 16) : (int)(val & 0xFFFFu);
+            if (iy < nty && sco == best_group) {
+                // ties: the candidate closest to the guess, then the lowest index (deterministic)
+                const int rt = (w >> 2) / NP;                                    // (rotation in the group) * ntx + x translation
+                const int ir = r0 + rt / ntx, itx = rt % ntx;
+                const int cnd = (ir * ntx + itx) * nty + iy;                     // index over all rotations
+                int dr = ir - a.n_coarse_rot, dx = itx - max(ktx, 0), dy = iy - max(kty, 0);
+                int key = ((dr * dr + dx * dx + dy * dy) << 16) | cnd;
+                atomicMin(&s_bestc, key);
+            }
         }
     }
     __syncthreads();
