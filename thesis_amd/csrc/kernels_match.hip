@@ -68,6 +68,10 @@ struct MatchArgs {
     double* ndt_aux;            // [particles][5] grid optimum (cells, cells, rad), its full score, ok flag
 };
 
+// two consecutive words of an occupancy mask row (4-byte aligned: one global_load_dwordx2)
+struct __attribute__((packed, aligned(4))) MaskPair { uint32_t lo, hi; };
+struct __attribute__((packed, aligned(4))) MaskTriple { uint32_t w0, w1, w2; };
+
 struct MatchLds {
     uint32_t* occ;      // [N][N/32]
     uint32_t* dil;      // [N][N/32]
@@ -221,9 +225,8 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                         const int t = s_tab[(rb >> 24) * v.L + lat];
                         if (t < 0) continue;
                         const uint32_t* row = v.occ + ((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow;
-                        const uint32_t w0 = row[wi], w1 = wi + 1 < v.ow ? row[wi + 1] : 0u, w2 = wi + 2 < v.ow ? row[wi + 2] : 0u,
-                                       w3 = wi + 3 < v.ow ? row[wi + 3] : 0u;
-                        const unsigned long long A = ((unsigned long long)w1 << 32) | w0, B = ((unsigned long long)w3 << 32) | w2;
+                        const MaskTriple m3 = *reinterpret_cast<const MaskTriple*>(row + wi);   // 64 columns from bit sft <= 32: three words
+                        const unsigned long long A = ((unsigned long long)m3.w1 << 32) | m3.w0, B = (unsigned long long)m3.w2;
                         unsigned long long b64 = sft == 0 ? A : (A >> sft) | (B << (64 - sft));
                         if (d64) {                                                              // columns stored one cell lower
                             const int s1 = sft - 1;
@@ -257,66 +260,69 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                 s.occ[u * W + wv] = bits;
             }
         } else {
-        const int SW = 8;                                       // region words per lane and pass (loads in flight)
-        const int WP = (W + 3) & ~3, GT = WP / 4;
+        // A wave takes 16 rows x 4 adjacent words at a time; a lane keeps its column word over a run of row blocks, so the
+        // column part of the address (tile column, window shift, defect bits) is worked out once per run.  The 32 columns
+        // of a fast word lie in two consecutive mask words: one 8-byte load.
+        const int SW = 4;                                       // rows per lane in flight
+        const int GT = (W + 3) / 4, NRB = N / 16;
         const unsigned slowg = (a.ds != 1 || W > 32 || v.match_stage_slow) ? 0xFFFFFFFFu : s_slowg;
-        for (int q0 = tid; q0 < N * WP; q0 += SW * MBLOCK) {
-            uint32_t lo[SW], hi[SW], hi2[SW]; int sh[SW], c0r[SW], uu[SW], ww[SW]; bool fast[SW];
-#pragma unroll
-            for (int k = 0; k < SW; ++k) {                      // issue the mask loads of SW words first
-                const int q = q0 + k * MBLOCK;
-                const int blk = q >> 6, l = q & 63;
-                const int u = (blk / GT) * 16 + (l & 15), wv = (blk % GT) * 4 + (l >> 4);
-                uu[k] = u; ww[k] = (q < N * WP && wv < W) ? wv : -1;
-                lo[k] = hi[k] = hi2[k] = 0; sh[k] = 0; c0r[k] = 0; fast[k] = false;
-                if (ww[k] < 0 || ((slowg >> wv) & 1u)) continue;
-                const uint32_t rb = rowbase[u];
-                if (rb == 0xFFFFFFFFu) continue;
-                fast[k] = true;
-                const int lat = colmap[wv * 32] >> 12;
-                const int t = s_tab[(rb >> 24) * v.L + lat];
-                if (t < 0) continue;
-                c0r[k] = (oy + wv * 32) - (lat - v.R) * v.dim + v.dim / 2;     // storage column of the word's first column
-                const int cy = max(c0r[k] - 1, 0);
-                const uint32_t* row = v.occ + ((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow;
-                lo[k] = row[cy >> 5];
-                hi[k] = ((cy >> 5) + 1 < v.ow) ? row[(cy >> 5) + 1] : 0u;
-                hi2[k] = ((cy >> 5) + 2 < v.ow) ? row[(cy >> 5) + 2] : 0u;
-                sh[k] = (cy >> 5) << 5;                         // first storage column of the loaded window
+        const int wave = tid >> 6, ln = tid & 63;
+        for (int g = 0; g < GT; ++g) {
+            const int wv = g * 4 + (ln >> 4);
+            const bool wv_ok = wv < W, fastw = wv_ok && !((slowg >> wv) & 1u);
+            int lat = 0, wi = 0, sft = 0; uint32_t d = 0;
+            if (fastw) {
+                lat = colmap[wv * 32] >> 12;
+                const int c0 = (oy + wv * 32) - (lat - v.R) * v.dim + v.dim / 2;       // storage column of the word's first column
+                wi = max(c0 - 1, 0) >> 5;                                               // the window starts one column lower (defects)
+                sft = c0 - (wi << 5);                                                   // 0..32
+                d = s_def[wv];                                                          // columns stored one cell lower
             }
+            for (int rb0 = wave; rb0 < NRB; rb0 += SW * (MBLOCK / 64)) {
+                MaskPair mp[SW];
 #pragma unroll
-            for (int k = 0; k < SW; ++k) {
-                if (ww[k] < 0) continue;
-                const int u = uu[k], wv = ww[k];
-                uint32_t bits;
-                if (fast[k]) {
-                    // 32 consecutive storage columns: a funnel shift of the loaded window, then the defect columns one by one
-                    const int sft = c0r[k] - sh[k];                                          // 0..32
-                    const unsigned long long w01 = ((unsigned long long)hi[k] << 32) | lo[k], w12 = ((unsigned long long)hi2[k] << 32) | hi[k];
-                    bits = sft < 32 ? (uint32_t)(w01 >> sft) : (uint32_t)(w12 >> (sft - 32));
-                    const uint32_t d = s_def[wv];                                            // columns stored one cell lower
-                    if (d) {
-                        const int s1 = sft - 1;
-                        const uint32_t below = s1 < 0 ? bits << 1 : s1 < 32 ? (uint32_t)(w01 >> s1) : (uint32_t)(w12 >> (s1 - 32));
-                        bits = (bits & ~d) | (below & d);
-                    }
-                } else {                                          // tile edge, unmapped column or coarser matcher cell: bit by bit
-                    bits = 0;
-                    for (int du = 0; du < a.ds; ++du) {
-                        const uint32_t rb = rowbase[u * a.ds + du];
-                        if (rb == 0xFFFFFFFFu) continue;
-                        for (int b = 0; b < 32 * a.ds; ++b) {
-                            const int e = colmap[wv * 32 * a.ds + b];
-                            if (e < 0) continue;
-                            const int t = s_tab[(rb >> 24) * v.L + (e >> 12)];
-                            if (t < 0) continue;
-                            const int cy = e & 0xFFF;
-                            const uint32_t wd = v.occ[((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow + (cy >> 5)];
-                            if ((wd >> (cy & 31)) & 1u) bits |= 1u << (b / a.ds);
+                for (int k = 0; k < SW; ++k) {                  // issue the mask loads of SW rows first
+                    const int rbk = rb0 + k * (MBLOCK / 64);
+                    mp[k].lo = 0; mp[k].hi = 0;
+                    if (rbk >= NRB || !fastw) continue;
+                    const uint32_t rb = rowbase[rbk * 16 + (ln & 15)];
+                    if (rb == 0xFFFFFFFFu) continue;
+                    const int t = s_tab[(rb >> 24) * v.L + lat];
+                    if (t < 0) continue;
+                    mp[k] = *reinterpret_cast<const MaskPair*>(v.occ + ((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow + wi);
+                }
+#pragma unroll
+                for (int k = 0; k < SW; ++k) {
+                    const int rbk = rb0 + k * (MBLOCK / 64), u = rbk * 16 + (ln & 15);
+                    if (rbk >= NRB || !wv_ok) continue;
+                    uint32_t bits;
+                    if (fastw) {
+                        // 32 consecutive storage columns: a funnel shift of the loaded window, then the defect columns
+                        const unsigned long long w01 = ((unsigned long long)mp[k].hi << 32) | mp[k].lo;
+                        bits = sft < 32 ? (uint32_t)(w01 >> sft) : mp[k].hi;
+                        if (d) {
+                            const int s1 = sft - 1;
+                            const uint32_t below = s1 < 0 ? bits << 1 : (uint32_t)(w01 >> s1);
+                            bits = (bits & ~d) | (below & d);
+                        }
+                    } else {                                      // tile edge, unmapped column or coarser matcher cell: bit by bit
+                        bits = 0;
+                        for (int du = 0; du < a.ds; ++du) {
+                            const uint32_t rb = rowbase[u * a.ds + du];
+                            if (rb == 0xFFFFFFFFu) continue;
+                            for (int b = 0; b < 32 * a.ds; ++b) {
+                                const int e = colmap[wv * 32 * a.ds + b];
+                                if (e < 0) continue;
+                                const int t = s_tab[(rb >> 24) * v.L + (e >> 12)];
+                                if (t < 0) continue;
+                                const int cy = e & 0xFFF;
+                                const uint32_t wd = v.occ[((size_t)t * v.dim + (rb & 0xFFFFFFu)) * v.ow + (cy >> 5)];
+                                if ((wd >> (cy & 31)) & 1u) bits |= 1u << (b / a.ds);
+                            }
                         }
                     }
+                    s.occ[u * W + wv] = bits;
                 }
-                s.occ[u * W + wv] = bits;
             }
         }
         }

@@ -217,7 +217,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.slot, P); ALLOC(h, v.global_id, P);
         v.ow = (dim + 31) / 32;
         ALLOC(h, v.tile_tab, P * LL); ALLOC(h, v.pool, (size_t)v.pool_tiles * cells);
-        ALLOC(h, v.occ, (size_t)v.pool_tiles * dim * v.ow);
+        ALLOC(h, v.occ, (size_t)v.pool_tiles * dim * v.ow + 4);       // (+4: the matcher's staging loads two / three words at a time)
         HIP_TRY(h, hipMemset(v.occ, 0, (size_t)v.pool_tiles * dim * v.ow * 4));
         ALLOC(h, v.tile_bbox, (size_t)v.pool_tiles * 4); ALLOC(h, v.free_stack, v.pool_tiles); ALLOC(h, v.free_top, 1);
         {   // the scan block: one device buffer, uploaded with one copy per scan (rbpf_set_scan)
