@@ -84,19 +84,29 @@ struct MatchLds {
 // the coarse map is stored with overlapping words: word h of a row holds coarse columns [16h, 16h + 32), so that any
 // 8 neighbouring columns lie inside ONE word
 __host__ __device__ inline int match_crs_words(int N) { return ((N / M_COARSE) + 15) / 16; }
+// ... and stored column-major with CRS_PAD zero rows on either side: crs[h * match_crs_stride(N) + CRS_PAD + cu], so that
+// the rows of consecutive x translations are consecutive words and a row outside the region reads 0 without a test
+static const int CRS_PAD = 7;
+__host__ __device__ inline int match_crs_stride(int N) { return N / M_COARSE + 2 * CRS_PAD; }
+__host__ __device__ inline int match_crs_total(int N) { return (match_crs_words(N) * match_crs_stride(N) + 3) & ~3; }
 
 // LDS of a match problem without its score table: occupancy + dilation bitmasks, the coarse map, the decimated beams
 static size_t match_lds_base(int N, int B) {
     size_t words = (size_t)N * (N / 32);
     size_t dec = (size_t)(((B + 3) / 4 + 7) & ~3) + (size_t)(((B + 7) / 8 + 7) & ~3);
-    return 2 * words * 4 + (size_t)(N / M_COARSE) * match_crs_words(N) * 4 + 16 + dec * 8 + 256;
+    return 2 * words * 4 + (size_t)match_crs_total(N) * 4 + dec * 8 + 256;
 }
 // The score table holds the coarse candidates of as many rotations as fit when TWO workgroups share a CU's 160 KB (the
 // kernel's instruction stream keeps one workgroup's eight waves busy half of the time), at least one rotation's
 // (`per_rot`) and the fine level's; the coarse level runs in groups of rotations.
+__global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a);
 size_t match_lds_bytes(int N, int B, int n_coarse, int per_rot) {
     const size_t fine = (size_t)(2 * M_FINE_R + 1) * (2 * M_FINE_T + 1) * (2 * M_FINE_T + 1);
-    const size_t base = match_lds_base(N, B), two_wg = (160 * 1024) / 2 - 2048;      // 2 KB: the kernel's static LDS
+    // half a CU's 160 KB less the kernel's static LDS (asked from the runtime; the LDS is handed out in 512-byte units)
+    size_t fixed = 2048;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(match_kernel)) == hipSuccess) fixed = (fa.sharedSizeBytes + 511) & ~(size_t)511;
+    const size_t base = match_lds_base(N, B), two_wg = (160 * 1024) / 2 - fixed;
     size_t nsc = (size_t)n_coarse;
     if (base + nsc * 4 > two_wg) nsc = base < two_wg ? (two_wg - base) / 4 : 0;
     if (nsc < (size_t)per_rot) nsc = (size_t)per_rot;
@@ -112,12 +122,6 @@ __device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w)
     uint32_t m = 1u << (w & 31);
     return ((s.occ[idx] & m) ? 1 : 0) + ((s.dil[idx] & m) ? 1 : 0);
 }
-__device__ __forceinline__ int coarse_hit(const MatchLds& s, int N, int u, int w) {
-    if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0;
-    int cu = u / M_COARSE, cw = w / M_COARSE;
-    return (s.crs[cu * match_crs_words(N) + (cw >> 4)] >> (cw & 15)) & 1u;
-}
-
 // guess, search window (robot.py:62-65) and region origin of one match problem
 __device__ inline void match_frame(const DevView& v, const MatchArgs& a, int p, double* g, double* rng, int* org) {
     double gx, gy, gth, rx, ry;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     s.dil = s.occ + (size_t)N * W;
     s.crs = s.dil + (size_t)N * W;
     const int cap4 = ((a.cap_sel + 3) / 4 + 7) & ~3, cap8 = ((a.cap_sel + 7) / 8 + 7) & ~3;
-    s.fx4 = reinterpret_cast<float*>(s.crs + (size_t)(N / M_COARSE) * match_crs_words(N) + 4); s.fy4 = s.fx4 + cap4;   // (+4: a zero word after the coarse map)
+    s.fx4 = reinterpret_cast<float*>(s.crs + match_crs_total(N)); s.fy4 = s.fx4 + cap4;
     s.cx8 = s.fy4 + cap4; s.cy8 = s.cx8 + cap8;
     s.sc = reinterpret_cast<int*>(s.cy8 + cap8);
     __shared__ double s_g[3], s_rng[2];
@@ -392,9 +396,12 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
             d = (d | (d >> 12)) & 0xFFu;                                 // eight bits
             out |= d << (8 * k);
         }
-        s.crs[q] = out;
+        s.crs[h * match_crs_stride(N) + CRS_PAD + cu] = out;
     }
-    if (tid == 0) s.crs[(N / M_COARSE) * match_crs_words(N)] = 0;       // looked up in place of cells outside the region
+    for (int q = tid; q < match_crs_words(N) * 2 * CRS_PAD; q += MBLOCK) {        // the zero rows before and after every column
+        const int h = q / (2 * CRS_PAD), r = q % (2 * CRS_PAD);
+        s.crs[h * match_crs_stride(N) + (r < CRS_PAD ? r : N / M_COARSE + r)] = 0;
+    }
     __syncthreads();
 
     const int nb = s_nb;
@@ -421,7 +428,6 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     // row of them: a work item is (rotation, beam slice); its per-candidate sums are byte lanes of two registers.
     const int n4 = ((nb + 3) / 4 + 3) & ~3;                                      // padded with far-away beams
     const float gthf = (float)remainder(gth, 6.283185307179586);
-    const int CW = match_crs_words(N);
     const int NC4 = N / M_COARSE;
     uint32_t* const sc2 = reinterpret_cast<uint32_t*>(s.sc);
     // ---- coarse level -------------------------------------------------------------------------------------------
@@ -436,7 +442,8 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     {
         const int MAXTX = 7;
         const int NSC = max(1, MBLOCK / nrg), nb8 = (nb + 7) / 8, per = (nb8 + NSC - 1) / NSC;   // beams per slice
-        const int ZERO = NC4 * CW;                                       // a word of the coarse map that is always 0
+        const int RS = match_crs_stride(N);
+        static_assert(MAXTX <= CRS_PAD, "the zero rows must cover a pass of x translations");
         for (int item = tid; item < nrg * NSC; item += MBLOCK) {
             const int irl = item / NSC, ir = r0 + irl, sl = item % NSC;
             float sn, cs;
@@ -450,17 +457,21 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
 #pragma unroll
                 for (int t = 0; t < MAXTX; ++t) { accA[t] = 0; accB[t] = 0; }
                 const int ge = min(g_hi, gg + 240);
+#pragma unroll 2
                 for (int g = gg; g < ge; ++g) {
                     const float bxs = s.cx8[g], bys = s.cy8[g];
                     const int cu0 = ((int)floorf(cs * bxs - sn * bys + fx) + (t0 - max(ktx, 0)) * M_COARSE) >> 2;   // x translation t looks at coarse row cu0 + t
                     const int cw0 = (int)floorf(sn * bxs + cs * bys + ty0) >> 2;             // candidate j looks at coarse column cw0 + j
-                    const bool col_ok = cw0 >= 0 && cw0 + 7 < NC4;
-                    const uint32_t sh = (uint32_t)(cw0 & 15);                                // one overlapping word holds all 8
-                    const int i00 = cu0 * CW + (cw0 >> 4);
+                    // the 7 rows are 7 consecutive words of one column of overlapping words (which holds all 8 candidates);
+                    // rows outside the region are zero rows, a beam outside altogether reads the zero rows of column 0
+                    const bool ok = cw0 >= 0 && cw0 + 7 < NC4 && (unsigned)(cu0 + CRS_PAD) < (unsigned)(NC4 + CRS_PAD);
+                    const uint32_t sh = (uint32_t)(cw0 & 15);
+                    int ci = (cw0 >> 4) * RS + (CRS_PAD + cu0);
+                    ci = ok ? ci : 0;
+                    const uint32_t* col = s.crs + ci;
 #pragma unroll
                     for (int t = 0; t < MAXTX; ++t) {
-                        const bool in = col_ok && (unsigned)(cu0 + t) < (unsigned)NC4;
-                        const uint32_t word = s.crs[in ? i00 + t * CW : ZERO];
+                        const uint32_t word = col[t];
                         accA[t] += (__builtin_amdgcn_ubfe(word, sh, 4u) * 0x00204081u) & 0x01010101u;
                         accB[t] += (__builtin_amdgcn_ubfe(word, sh + 4u, 4u) * 0x00204081u) & 0x01010101u;
                     }
