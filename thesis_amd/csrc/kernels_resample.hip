@@ -295,11 +295,16 @@ __global__ __launch_bounds__(COPY_BLOCK) void resample_copy_kernel(CopyArgs a) {
     const int tid = threadIdx.x;
     const int LL = v.L * v.L;
     const size_t cells = (size_t)v.dim * v.dim;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) s_item = atomicAdd(&a.n_jobs[1], 1);
-        __syncthreads();
-        const int job = s_item;
+    // a workgroup's first job is its own index; only the jobs beyond the grid go through the queue head (one returning atomic
+    // on one address per workgroup and job is a chain of L2 round trips that 512 workgroups would stand in line for)
+    for (int round = 0;; ++round) {
+        int job = blockIdx.x;
+        if (round > 0) {
+            __syncthreads();
+            if (tid == 0) s_item = (int)gridDim.x + atomicAdd(&a.n_jobs[1], 1);
+            __syncthreads();
+            job = s_item;
+        }
         if (job >= a.n_jobs[0]) return;
         const int src_slot = a.jobs[2 * job], dst_slot = a.jobs[2 * job + 1];
         if (tid < LL) { s_ts[tid] = v.tile_tab[(size_t)src_slot * LL + tid]; s_td[tid] = v.tile_tab[(size_t)dst_slot * LL + tid]; }
