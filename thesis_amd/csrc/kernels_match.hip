@@ -692,7 +692,6 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
 // The reference cloud is the occupancy bitmask itself: the points of an NDT cell are the centres of its occupied
 // matcher cells, so a cell's mean and covariance follow from integer sums over its nc x nc bits.
 struct NdtCell { double mx, my, b00, b01, b11; };          // mean (offset from the cell's first matcher cell), inverse covariance
-struct NdtCellF { double mx, my; float b00, b01, b11, pad; };   // the table entry of the single-precision path (32 bytes)
 __device__ inline bool ndt_cell_stats(int n, int sx, int sy, int sxx, int sxy, int syy, NdtCell& c) {
     if (n < 3) return false;
     const double nn = (double)n, mx = (double)sx / nn, my = (double)sy / nn;
@@ -724,26 +723,59 @@ __device__ __forceinline__ void ndt_term(const NdtCell& c, double qx0, double qy
     m[8] += sg * (-c1 * c2 + bj1);
     m[9] += sg * (-c2 * c2 + (-ry) * bj0 + rx * bj1 + e0 * (-rx) + e1 * (-ry));
 }
-// The same term in single precision (the hot form): the offset from the cell mean is formed in double (coordinates
-// run to hundreds of cells) and is small; everything after it is float, summed per thread in float and across threads in
-// double.  oracle/matcher_oracle.py follows the same split.
-__device__ __forceinline__ void ndt_term32(float b00, float b01, float b11, float dx, float dy, float rx, float ry, float live, float* m) {
-    const float e0 = b00 * dx + b01 * dy, e1 = b01 * dx + b11 * dy;
-    const float sg = live * expf(-0.5f * (dx * e0 + dy * e1));
-    const float c0 = e0, c1 = e1, c2 = e0 * (-ry) + e1 * rx;
-    const float bj0 = b00 * (-ry) + b01 * rx, bj1 = b01 * (-ry) + b11 * rx;
+// The same term in single precision, two NDT cells at a time (the hot form, nc == 2): the offset from the cell mean comes
+// from the beam's fractional position (formed in double: coordinates run to hundreds of cells) and is small; everything after
+// it is packed float arithmetic with fused multiply-adds, summed per thread in float and across threads in double.
+// oracle/matcher_oracle.py states the same formulas (float32 terms, float64 sums); the two agree to ~1e-7, not bit for bit.
+// A cell without a Gaussian has a far-away mean in the table (NDT_FAR): its weight underflows to exactly 0.
+typedef float ndt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ndt_f2 ndt_fma2(ndt_f2 a, ndt_f2 b, ndt_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+static const float NDT_FAR = 1.0e6f;
+__device__ __forceinline__ void ndt_term_pair(ndt_f2 b00, ndt_f2 b01, ndt_f2 b11, ndt_f2 dx, ndt_f2 dy, float rxs, float rys, ndt_f2* m) {
+    const ndt_f2 rx = {rxs, rxs}, ry = {rys, rys};
+    const ndt_f2 e0 = ndt_fma2(b01, dy, b00 * dx), e1 = ndt_fma2(b11, dy, b01 * dx);
+    const ndt_f2 q = ndt_fma2(dy, e1, dx * e0) * -0.5f;
+    const ndt_f2 sg = {__expf(q.x), __expf(q.y)};
+    const ndt_f2 c2 = ndt_fma2(e1, rx, -(e0 * ry));
+    const ndt_f2 bj0 = ndt_fma2(b01, rx, -(b00 * ry)), bj1 = ndt_fma2(b11, rx, -(b01 * ry));
     m[0] -= sg;
-    m[1] += sg * c0; m[2] += sg * c1; m[3] += sg * c2;
-    m[4] += sg * (-c0 * c0 + b00);
-    m[5] += sg * (-c0 * c1 + b01);
-    m[6] += sg * (-c0 * c2 + bj0);
-    m[7] += sg * (-c1 * c1 + b11);
-    m[8] += sg * (-c1 * c2 + bj1);
-    m[9] += sg * (-c2 * c2 + (-ry) * bj0 + rx * bj1 + e0 * (-rx) + e1 * (-ry));
+    m[1] = ndt_fma2(sg, e0, m[1]); m[2] = ndt_fma2(sg, e1, m[2]); m[3] = ndt_fma2(sg, c2, m[3]);
+    m[4] = ndt_fma2(sg, ndt_fma2(-e0, e0, b00), m[4]);
+    m[5] = ndt_fma2(sg, ndt_fma2(-e0, e1, b01), m[5]);
+    m[6] = ndt_fma2(sg, ndt_fma2(-e0, c2, bj0), m[6]);
+    m[7] = ndt_fma2(sg, ndt_fma2(-e1, e1, b11), m[7]);
+    m[8] = ndt_fma2(sg, ndt_fma2(-e1, c2, bj1), m[8]);
+    const ndt_f2 h = ndt_fma2(rx, bj1, -(ry * bj0)) - ndt_fma2(e1, ry, e0 * rx);
+    m[9] = ndt_fma2(sg, ndt_fma2(-c2, c2, h), m[9]);
 }
+// the NDT kernel's copy of the field has a zero row above and below and a zero word left and right of every row
 __device__ __forceinline__ uint32_t ndt_bit(const uint32_t* occ, int N, int u, int w) {
     if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0u;
-    return (occ[u * (N >> 5) + (w >> 5)] >> (w & 31)) & 1u;
+    return (occ[(u + 1) * ((N >> 5) + 2) + (w >> 5) + 1] >> (w & 31)) & 1u;
+}
+// sum over the wave's 64 lanes, complete in lane 63: four steps inside the rows of 16 lanes and two broadcasts of a row's
+// last lane, all through the data-parallel-primitive path (no LDS round trips)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double ndt_dpp_f64(double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    int lo, hi;
+    if (ROW_MASK == 0xF) {                   // every lane reads a lane: no value needed for the rows that stay out
+        lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    }
+    return __builtin_bit_cast(double, ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double ndt_wave_sum63(double x) {
+    x += ndt_dpp_f64<0xB1, 0xF>(x);          // quad_perm [1,0,3,2]
+    x += ndt_dpp_f64<0x4E, 0xF>(x);          // quad_perm [2,3,0,1]
+    x += ndt_dpp_f64<0x141, 0xF>(x);         // row_half_mirror
+    x += ndt_dpp_f64<0x140, 0xF>(x);         // row_mirror: every lane of a row holds the row's sum
+    x += ndt_dpp_f64<0x142, 0xA>(x);         // row_bcast:15 into rows 1 and 3
+    x += ndt_dpp_f64<0x143, 0xC>(x);         // row_bcast:31 into rows 2 and 3
+    return x;
 }
 // One beam at the pose (tx, ty, theta), region cell units; four overlapping grids shifted by half an NDT cell and
 // anchored to the global cell index: the general form.  (nc == 2, i.e. 0.05 m matcher cells -- every shipped
@@ -792,7 +824,7 @@ __device__ inline bool ndt_lm_step(const double* m, double lam, double* d) {
 static const int NBLOCK = 256;            // NDT kernel: threads per particle
 static const int NDT_STRIDE = 1;          // beams used by the ascent (1: all; the final score always uses all)
 
-size_t ndt_lds_bytes(int N, int B) { (void)B; return (size_t)N * (N / 32) * 4 + 64; }    // the field only: four workgroups per CU at N = 512
+size_t ndt_lds_bytes(int N, int B) { (void)B; return (size_t)(N + 2) * (N / 32 + 2) * 4 + 64; }    // the field with its zero border only: four workgroups per CU at N = 512
 
 // The second matcher stage (matchScanCustom.m:32-50) for the particles whose grid stage succeeded: damped Newton ascent
 // of the NDT score from the grid optimum.  Thread 0 holds the optimiser state; every evaluation is one pass over the
@@ -806,7 +838,7 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
     const float inv = (float)(1.0 / a.mcs);     // matcher cells per metre, float as the grid stage stages its beams
     __shared__ double s_g[3], s_rng[2], s_trial[6], s_w[NBLOCK / 64][10];     // s_trial: pose, -, sin, cos
     __shared__ int s_org[2], s_go;
-    __shared__ NdtCellF s_lut[16];              // statistics of a 2 x 2 NDT cell by occupancy pattern
+    __shared__ float s_lut[5][16];              // a 2 x 2 NDT cell by occupancy pattern: 0.5 + mean x, 0.5 + mean y, inverse covariance (3)
     __shared__ unsigned s_ok;
 #ifdef RBPF_STAMPS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
@@ -815,17 +847,27 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
     const double* aux = a.ndt_aux + (size_t)p * 5;
     if (aux[4] == 0.0 || a.n_sel <= 0) return;                  // the grid stage failed: matchScanCustom.m:25-28, uniform
     if (tid == 0) { match_frame(v, a, p, s_g, s_rng, s_org); s_ok = 0; }
+    const int WPD = W + 2;                                      // words of a row of the bordered field
     {
         const uint32_t* src = a.ndt_occ + (size_t)p * N * W;
-        for (int i = tid; i < N * W; i += NBLOCK) occ[i] = src[i];
+        int u = tid / W, wv = tid % W;                          // (one division; the position then advances by NBLOCK words)
+        const int du = NBLOCK / W, dw = NBLOCK % W;
+        for (int i = tid; i < N * W; i += NBLOCK) {
+            occ[(u + 1) * WPD + wv + 1] = src[i];
+            u += du; wv += dw;
+            if (wv >= W) { wv -= W; ++u; }
+        }
+        for (int i = tid; i < WPD; i += NBLOCK) { occ[i] = 0; occ[(N + 1) * WPD + i] = 0; }
+        for (int i = tid; i < N; i += NBLOCK) { occ[(i + 1) * WPD] = 0; occ[(i + 1) * WPD + W + 1] = 0; }
     }
     __syncthreads();
     if (tid < 16) {             // pattern bit 0: cell (0,0), bit 1: (0,1), bit 2: (1,0), bit 3: (1,1)
         const int b0 = tid & 1, b1 = (tid >> 1) & 1, b2 = (tid >> 2) & 1, b3 = (tid >> 3) & 1;
         NdtCell c = {0, 0, 0, 0, 0};
-        if (ndt_cell_stats(b0 + b1 + b2 + b3, b2 + b3, b1 + b3, b2 + b3, b3, b1 + b3, c)) atomicOr(&s_ok, 1u << tid);
-        NdtCellF f = {c.mx, c.my, (float)c.b00, (float)c.b01, (float)c.b11, 0.0f};
-        s_lut[tid] = f;
+        const bool okc = ndt_cell_stats(b0 + b1 + b2 + b3, b2 + b3, b1 + b3, b2 + b3, b3, b1 + b3, c);
+        if (okc) atomicOr(&s_ok, 1u << tid);
+        s_lut[0][tid] = okc ? (float)(0.5 + c.mx) : NDT_FAR; s_lut[1][tid] = okc ? (float)(0.5 + c.my) : NDT_FAR;
+        s_lut[2][tid] = okc ? (float)c.b00 : 1.0f; s_lut[3][tid] = okc ? (float)c.b01 : 0.0f; s_lut[4][tid] = okc ? (float)c.b11 : 1.0f;
     }
     const int ox = s_org[0], oy = s_org[1], nb = a.n_sel, nc = a.ndt_nc;
     const double gth = s_g[2];
@@ -842,65 +884,62 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
     if (tid == 0) { s_trial[0] = ndt_p[0]; s_trial[1] = ndt_p[1]; s_trial[2] = ndt_p[2]; sincos(ndt_p[2], &s_trial[4], &s_trial[5]); s_go = 1; }
     __syncthreads();
     MSTAMP(0);                                   // staging
-    const unsigned lut_ok = s_ok;
     // one evaluation: every `stride`-th beam at the pose in s_trial; per-wave sums land in s_w (then a barrier)
     auto evaluate = [&](int stride) {
         const double tx = s_trial[0], ty = s_trial[1], snd = s_trial[4], csd = s_trial[5];
         double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const int nbs = (nb + stride - 1) / stride;
         if (nc == 2) {
-            // one beam per lane and pass; its four grid terms are independent chains (branch-free: a term without a
-            // Gaussian is multiplied by zero), which is what hides the LDS and exp latencies
-            float mf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // One beam per lane and pass.  The four NDT cells that hold a point (one per shifted grid) are the four 2 x 2
+            // windows of the 3 x 3 cells round it, whatever the grids' phase: two packed pairs of terms, no branches.
+            ndt_f2 mf[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) mf[k] = ndt_f2{0.0f, 0.0f};
             for (int i = tid; i < nbs; i += NBLOCK) {
                 const int b = i * stride;
                 const double bxd = (double)(bx[b] * inv), byd = (double)(by[b] * inv);
                 const double rx = csd * bxd - snd * byd, ry = snd * bxd + csd * byd;
                 const double ex = rx + tx, ey = ry + ty;
-                const int u = (int)floor(ex), w = (int)floor(ey);
+                const double fu = floor(ex), fw = floor(ey);
+                const int u = (int)fu, w = (int)fw;
                 const bool inside = (unsigned)u < (unsigned)N && (unsigned)w < (unsigned)N;
-                // the 3 x 3 occupancy bits around the beam's cell: bit 3 * r + c = cell (u - 1 + r, w - 1 + c)
+                const float fxr = (float)(ex - fu), fyr = (float)(ey - fw);          // position inside the cell, [0, 1)
+                // the 3 x 3 occupancy bits round the beam's cell: bit 3 r + c = cell (u - 1 + r, w - 1 + c); the border of
+                // zeros makes every address valid once (u, w) is clamped into the region
                 uint32_t nb9 = 0;
                 {
-                    const int c0 = w - 1, wi = max(c0, 0) >> 5;
-                    uint32_t lo[3], hi[3];
+                    const int uc = min(max(u, 0), N - 1), c0 = min(max(w, 0), N - 1) - 1;     // first column, -1 .. N - 2
+                    const uint32_t* row = occ + uc * WPD + ((c0 >> 5) + 1);
+                    const uint32_t sh = (uint32_t)(c0 & 31);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const int uu = u - 1 + r;
-                        const bool rok = inside && (unsigned)uu < (unsigned)N;
-                        const int base = (rok ? uu : 0) * W + (inside ? wi : 0);
-                        lo[r] = rok ? occ[base] : 0u;
-                        hi[r] = (rok && wi + 1 < W) ? occ[base + 1] : 0u;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const unsigned long long q = ((unsigned long long)hi[r] << 32) | lo[r];
-                        const uint32_t three = c0 < 0 ? ((uint32_t)q << 1) & 7u : (uint32_t)(q >> (c0 & 31)) & 7u;
-                        nb9 |= three << (3 * r);
-                    }
+                    for (int r = 0; r < 3; ++r)
+                        nb9 |= (__builtin_amdgcn_alignbit(row[r * WPD + 1], row[r * WPD], sh) & 7u) << (3 * r);
+                    nb9 = inside ? nb9 : 0u;
                 }
                 const float rxf = (float)rx, ryf = (float)ry;
+                const float x1 = fxr + 1.0f, y1 = fyr + 1.0f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int mu = (u + ox - (g & 1)) & 1, mw = (w + oy - ((g >> 1) & 1)) & 1;     // offset inside the NDT cell
-                    const int sh = 3 * (1 - mu) + (1 - mw);
-                    const uint32_t pat = ((nb9 >> sh) & 3u) | (((nb9 >> (sh + 3)) & 3u) << 2);
-                    const bool okg = inside && ((lut_ok >> pat) & 1u);
-                    const NdtCellF c = s_lut[pat];
-                    const float dx = (float)(ex - ((double)(u - mu) + 0.5 + c.mx)), dy = (float)(ey - ((double)(w - mw) + 0.5 + c.my));
-                    ndt_term32(c.b00, c.b01, c.b11, dx, dy, rxf, ryf, okg ? 1.0f : 0.0f, mf);
+                for (int a2 = 0; a2 < 2; ++a2) {                // windows (a2, 0) and (a2, 1): rows u - 1 + a2 .., columns w - 1 .. / w ..
+                    const uint32_t pA = ((nb9 >> (3 * a2)) & 3u) | ((nb9 >> (3 * a2 + 1)) & 12u);
+                    const uint32_t pB = ((nb9 >> (3 * a2 + 1)) & 3u) | ((nb9 >> (3 * a2 + 2)) & 12u);
+                    const ndt_f2 cx = {s_lut[0][pA], s_lut[0][pB]}, cy = {s_lut[1][pA], s_lut[1][pB]};
+                    const ndt_f2 b00 = {s_lut[2][pA], s_lut[2][pB]}, b01 = {s_lut[3][pA], s_lut[3][pB]}, b11 = {s_lut[4][pA], s_lut[4][pB]};
+                    const float xs = a2 ? fxr : x1;
+                    const ndt_f2 dx = ndt_f2{xs, xs} - cx, dy = ndt_f2{y1, fyr} - cy;
+                    ndt_term_pair(b00, b01, b11, dx, dy, rxf, ryf, mf);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 10; ++k) m[k] = (double)mf[k];
+            for (int k = 0; k < 10; ++k) m[k] = (double)mf[k].x + (double)mf[k].y;
         } else {
             for (int i = tid; i < nbs; i += NBLOCK) ndt_point(occ, N, nc, ox, oy, (double)(bx[i * stride] * inv), (double)(by[i * stride] * inv), tx, ty, snd, csd, m);
         }
         MSTAMP(1);                               // beams
-        for (int k = 0; k < 10; ++k) {
-            double x = m[k];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-            if ((tid & 63) == 0) s_w[tid >> 6][k] = x;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) m[k] = ndt_wave_sum63(m[k]);
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) s_w[tid >> 6][k] = m[k];
         }
         __syncthreads();
         MSTAMP(2);                               // reduction + barrier
