@@ -69,8 +69,8 @@ def _cell_stats(occ: np.ndarray, u0: np.ndarray, w0: np.ndarray, nc: int):
 def ndt_eval(occ: np.ndarray, pts: np.ndarray, p, nc: int, ox: int, oy: int, single: bool = False):
     """f = -score, gradient (3), Hessian (6: xx xy xt yy yt tt) at p = (tx, ty, theta).
 
-    ``single``: the kernel's hot form for nc == 2 -- the offset from the cell mean is formed in float64, everything
-    after it in float32 (sums in float64)."""
+    ``single``: the kernel's hot form for nc == 2 -- the offset from the cell mean is formed from the point's float32
+    position inside its matcher cell, everything after it in float32 (sums in float64)."""
     tx, ty, th = p
     sn, cs = np.sin(th), np.cos(th)
     bx, by = pts[:, 0], pts[:, 1]
@@ -89,8 +89,14 @@ def ndt_eval(occ: np.ndarray, pts: np.ndarray, p, nc: int, ox: int, oy: int, sin
         ok &= live
         dx, dy = ex - qx, ey - qy
         if single:
+            # the kernel's form: position inside the matcher cell (float64 -> float32) plus the cell's offset inside the NDT
+            # cell, minus the table's float32 "0.5 + mean"; the terms are float32 (the kernel fuses multiply-adds and uses
+            # the hardware exponential: agreement to ~1e-7, not bit for bit)
             f32 = np.float32
-            dx, dy, B00, B01, B11 = dx.astype(f32), dy.astype(f32), B00.astype(f32), B01.astype(f32), B11.astype(f32)
+            fx, fy = (ex - np.floor(ex)).astype(f32), (ey - np.floor(ey)).astype(f32)
+            dx = (fx + (u - u0).astype(f32)) - (qx - u0).astype(f32)
+            dy = (fy + (w - w0).astype(f32)) - (qy - w0).astype(f32)
+            B00, B01, B11 = B00.astype(f32), B01.astype(f32), B11.astype(f32)
             rx, ry = rx.astype(f32), ry.astype(f32)
             e0, e1 = B00 * dx + B01 * dy, B01 * dx + B11 * dy
             s = np.where(ok, np.exp(f32(-0.5) * (dx * e0 + dy * e1)), f32(0.0))

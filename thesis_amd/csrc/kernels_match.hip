@@ -852,10 +852,20 @@ __global__ __launch_bounds__(NBLOCK, 4) void ndt_kernel(DevView v, MatchArgs a) 
         const uint32_t* src = a.ndt_occ + (size_t)p * N * W;
         int u = tid / W, wv = tid % W;                          // (one division; the position then advances by NBLOCK words)
         const int du = NBLOCK / W, dw = NBLOCK % W;
-        for (int i = tid; i < N * W; i += NBLOCK) {
-            occ[(u + 1) * WPD + wv + 1] = src[i];
-            u += du; wv += dw;
-            if (wv >= W) { wv -= W; ++u; }
+        const int SL = 16;                                      // loads in flight per thread
+        for (int i0 = tid; i0 < N * W; i0 += SL * NBLOCK) {
+            uint32_t val[SL]; int dst[SL];
+#pragma unroll
+            for (int k = 0; k < SL; ++k) {
+                const int i = i0 + k * NBLOCK;
+                val[k] = i < N * W ? src[i] : 0u;
+                dst[k] = (u + 1) * WPD + wv + 1;
+                u += du; wv += dw;
+                if (wv >= W) { wv -= W; ++u; }
+            }
+#pragma unroll
+            for (int k = 0; k < SL; ++k)
+                if (i0 + k * NBLOCK < N * W) occ[dst[k]] = val[k];
         }
         for (int i = tid; i < WPD; i += NBLOCK) { occ[i] = 0; occ[(N + 1) * WPD + i] = 0; }
         for (int i = tid; i < N; i += NBLOCK) { occ[(i + 1) * WPD] = 0; occ[(i + 1) * WPD + W + 1] = 0; }
