@@ -16,6 +16,13 @@
 
 namespace rbpf {
 
+#ifdef RBPF_STAMPS
+#define PSTAMP(k) do { if (threadIdx.x == 0) { long long t_ = clock64(); atomicAdd(&v.stats[8 + (k)], (unsigned long long)(t_ - st_prev)); st_prev = t_; } } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+
+
 static const int KMAX = 32;
 
 // ---- Philox4x32-10 ---------------------------------------------------------------------------------
@@ -132,11 +139,14 @@ __global__ __launch_bounds__(64) void propose_prep_kernel(DevView v, ProposeArgs
 struct WeightFrame {
     const double* s_c; const double* s_s; const double (*s_g)[3]; const float4* s_q; int* s_sum;
     const int* s_tab; const unsigned long long* s_base;
+    uint32_t* s_redo; int* s_nredo;                    // queue of the look-ups that go the float64 way: beam << 5 | sample
+    float* s_bx; float* s_by;                          // the beams that count (robot.py:130), single precision: a chunk of DevView::wsel_x / wsel_y
 };
-__device__ __forceinline__ void weight_beams(const DevView& v, const HomeTile& home, const WeightFrame& f, int K, int tid) {
+static const int REDO_CAP = 2048;
+static const int WB_CAP = 1536;                        // beams staged at a time
+__device__ __forceinline__ void weight_beams(const DevView& v, const HomeTile& home, const WeightFrame& f, int K, int tid, long long& st_prev) {
     const double* const s_c = f.s_c; const double* const s_s = f.s_s; const double (*s_g)[3] = f.s_g; const float4* const s_q = f.s_q;
     int* const s_sum = f.s_sum; const int* const s_tab = f.s_tab; const unsigned long long* const s_base = f.s_base;
-    const double inv_cs = (double)v.dim / v.tile_len;
     // (the home tile's address is the same for the whole workgroup: kept in scalar registers, so that a look-up is a
     // 32-bit offset from a scalar base - no 64-bit address arithmetic per load)
     typedef __attribute__((address_space(1))) const int8_t global_i8;
@@ -148,33 +158,54 @@ __device__ __forceinline__ void weight_beams(const DevView& v, const HomeTile& h
     }
     const float WSAFE = v.wsafe_override >= 0.0f ? v.wsafe_override : (v.dim <= 1024 ? 1e-3f : 2e-3f);   // (the override is a test knob: RBPF_WSAFE)
     const bool f32_ok = home.ok && v.dim <= 2048;
-    // Work split: four lanes share a beam, each takes eight of the (up to 32) samples; 64 beams per pass of the workgroup.
-    // 1081 beams are 17 passes with the last one 89 % full (a thread per beam and all samples: 5 passes, the last 22 %
-    // full), and the sums of a sample meet in the lanes that are four apart.
-    {
-        const int k0 = 8 * (tid & 3);                                 // this lane's samples k0 .. k0 + 7
-        int acc[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = 0;
-        for (int b = tid >> 2; b < v.B && k0 < K; b += BLOCK / 4) {
-            if (!(v.bflags[b] & BF_WEIGHT)) continue;                 // robot.py:130
-            const double x = v.bx[b], y = v.by[b];
-            const float x32 = (float)x, y32 = (float)y;
-            const bool beam_ok = f32_ok && (fabsf(x32) + fabsf(y32)) * (float)inv_cs <= 1.5f * (float)v.dim;   // the error budget's premise
-            uint32_t redo = 0;
+    // Work split: a lane is a SAMPLE (32 lanes = the up to 32 samples of one beam, two beams per wave, eight per pass of the
+    // workgroup).  The samples of a beam end within a few cells of each other, so the 64 byte loads of one instruction fall into
+    // a dozen cache lines instead of one per lane - the texture unit takes a line per cycle - and a lane keeps its sample's frame
+    // in registers and its sum to itself.  The beams that count (robot.py:130) are packed into LDS first, single precision; a
+    // beam outside the error budget's premise is stored as NaN: every look-up of it fails the fast test and goes the exact way.
+    const int k = tid & 31, grp = tid >> 5;
+    const bool live = k < K;
+    typedef float wf2 __attribute__((ext_vector_type(2)));
+    const float4 q = s_q[min(k, K - 1)];
+    const wf2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z}, qw = {q.w, q.w};
+    int acc = 0;
+    const int n_all = v.n_wsel, npad_all = (n_all + 63) & ~63;        // (the list is padded with NaN to whole passes: fails the fast test, dropped on the slow way)
+    for (int c0 = 0; c0 < npad_all; c0 += WB_CAP) {
+        const int n = min(n_all - c0, WB_CAP), npad = min(npad_all - c0, WB_CAP);
+        __syncthreads();
+        for (int j = 4 * tid; j < npad; j += 4 * BLOCK) {
+            float4 x4 = *reinterpret_cast<const float4*>(v.wsel_x + c0 + j);
+            if (!f32_ok) x4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            *reinterpret_cast<float4*>(f.s_bx + j) = x4;
+            *reinterpret_cast<float4*>(f.s_by + j) = *reinterpret_cast<const float4*>(v.wsel_y + c0 + j);
+        }
+        __syncthreads();
+        PSTAMP(1);
+        // a group of 32 lanes takes eight neighbouring beams per pass: two 16-byte LDS reads per coordinate, packed arithmetic on pairs
+        if (live)
+        for (int j0 = 8 * grp; j0 < npad; j0 += 8 * (BLOCK / 32)) {
             uint32_t addr[8]; bool fast[8];
+            const float4 xa = *reinterpret_cast<const float4*>(f.s_bx + j0), xb = *reinterpret_cast<const float4*>(f.s_bx + j0 + 4);
+            const float4 ya = *reinterpret_cast<const float4*>(f.s_by + j0), yb = *reinterpret_cast<const float4*>(f.s_by + j0 + 4);
+            const wf2 bx2[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xb.x, xb.y}, {xb.z, xb.w}}, by2[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}};
+            uint32_t redo = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = k0 + u < K;
-                const float4 q = s_q[min(k0 + u, K - 1)];
-                const float cx = fmaf(q.x, x32, fmaf(-q.y, y32, q.z)), cy = fmaf(q.y, x32, fmaf(q.x, y32, q.w));   // lidar.py:123, in cells
-                const float fx = floorf(cx), fy = floorf(cy);
-                const int ix = (int)fx, iy = (int)fy;
-                const float rx = cx - fx, ry = cy - fy;
-                // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
-                fast[u] = ((int)beam_ok & (int)live & (int)(fminf(rx, ry) > WSAFE) & (int)(fmaxf(rx, ry) < 1.0f - WSAFE) & (int)(max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim)) != 0;
-                addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
-                if (live && !fast[u]) redo |= 1u << u;
+            for (int h = 0; h < 4; ++h) {
+                const wf2 cx2 = __builtin_elementwise_fma(qx, bx2[h], __builtin_elementwise_fma(-qy, by2[h], qz));   // lidar.py:123, in cells
+                const wf2 cy2 = __builtin_elementwise_fma(qy, bx2[h], __builtin_elementwise_fma(qx, by2[h], qw));
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = 2 * h + e;
+                    const float cx = e ? cx2.y : cx2.x, cy = e ? cy2.y : cy2.x;
+                    int ix, iy;                                       // floor to int32 in one instruction
+                    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(cx));
+                    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(cy));
+                    const float rx = __builtin_amdgcn_fractf(cx), ry = __builtin_amdgcn_fractf(cy);   // x - floor(x)
+                    // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
+                    fast[u] = ((int)(fminf(rx, ry) > WSAFE) & (int)(fmaxf(rx, ry) < 1.0f - WSAFE) & (int)(max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim)) != 0;
+                    addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
+                    redo |= fast[u] ? 0u : 1u << u;
+                }
             }
             int val[8];
 #pragma unroll
@@ -183,23 +214,41 @@ __device__ __forceinline__ void weight_beams(const DevView& v, const HomeTile& h
             // select that uses it and wait for it there, one load at a time)
             asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += fast[u] ? val[u] : 0;
-            while (redo) {                                            // float64, the reference's operations
-                const int k = k0 + __ffs(redo) - 1;
-                redo &= redo - 1;
-                const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];   // lidar.py:123
-                const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
-                int vv;
-                if (lookup_cell_home(v, home, s_tab, s_base, gx, gy, vv)) atomicAdd(&s_sum[k], vv);
+            for (int u = 0; u < 8; ++u) acc += fast[u] ? val[u] : 0;
+            // The look-ups that need the reference's float64 operations (under 1 % of them, but some lane of a wave has one in
+            // most passes) are queued and done after the loop with all lanes busy; a full queue: done here.
+            if (redo) {
+                for (uint32_t r = redo; r; r &= r - 1) if (j0 + __ffs(r) - 1 >= n) redo &= ~(r & -r);     // (padding)
+                const int nr = __popc(redo);
+                int slot = nr ? atomicAdd(f.s_nredo, nr) : 0;
+                const bool queued = slot + nr <= REDO_CAP;
+                if (nr && !queued && slot <= REDO_CAP) f.s_nredo[1] = slot; // the first push that does not fit: the queue ends here
+                for (uint32_t r = redo; r; r &= r - 1) {
+                    const int b = (int)v.wsel_idx[c0 + j0 + __ffs(r) - 1];
+                    if (queued) { f.s_redo[slot++] = (uint32_t)b << 5 | (uint32_t)k; continue; }
+                    const double x = v.bx[b], y = v.by[b];
+                    const double gx = (s_c[k] * x + (-s_s[k]) * y) + s_g[k][0];   // lidar.py:123
+                    const double gy = (s_s[k] * x + s_c[k] * y) + s_g[k][1];
+                    int vv;
+                    if (lookup_cell_home(v, home, s_tab, s_base, gx, gy, vv)) acc += vv;
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int s = acc[u];
-            for (int off = 32; off >= 4; off >>= 1) s += __shfl_xor(s, off, 64);      // the lanes with the same samples
-            if ((tid & 63) < 4 && k0 + u < K) atomicAdd(&s_sum[k0 + u], s);
-        }
     }
+    if (live && acc) atomicAdd(&s_sum[k], acc);
+    __syncthreads();
+    PSTAMP(2);
+    const int n_redo = f.s_nredo[0] <= REDO_CAP ? f.s_nredo[0] : f.s_nredo[1];
+    for (int i = tid; i < n_redo; i += BLOCK) {                       // float64, the reference's operations
+        const uint32_t e = f.s_redo[i];
+        const int b = (int)(e >> 5), kk = (int)(e & 31u);
+        const double x = v.bx[b], y = v.by[b];
+        const double gx = (s_c[kk] * x + (-s_s[kk]) * y) + s_g[kk][0];   // lidar.py:123
+        const double gy = (s_s[kk] * x + s_c[kk] * y) + s_g[kk][1];
+        int vv;
+        if (lookup_cell_home(v, home, s_tab, s_base, gx, gy, vv)) atomicAdd(&s_sum[kk], vv);
+    }
+    PSTAMP(3);
 }
 
 __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, ProposeArgs a) {
@@ -210,8 +259,12 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
     __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
     __shared__ double s_mom[16];                       // moments: mean[3], norm, sig[9], min_w
-    __shared__ int s_bad;
+    __shared__ int s_bad, s_nredo[2];
+    __shared__ uint32_t s_redo[REDO_CAP];
+    __shared__ __align__(16) float s_bx[WB_CAP], s_by[WB_CAP];
     const int p = blockIdx.x, tid = threadIdx.x, K = v.K;
+    long long st_prev = clock64();
+    if (tid == 0) { s_nredo[0] = 0; s_nredo[1] = 0; }
     const int LL = v.L * v.L;
     {   // the frame propose_prep_kernel left
         const double* pr = v.prop_prep + (size_t)p * PREP_W;
@@ -256,8 +309,9 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     __syncthreads();
 
     {
-        const WeightFrame wf{s_c, s_s, s_g, s_q, s_sum, s_tab, s_base};
-        weight_beams(v, home, wf, K, tid);
+        const WeightFrame wf{s_c, s_s, s_g, s_q, s_sum, s_tab, s_base, s_redo, s_nredo, s_bx, s_by};
+        PSTAMP(0);
+        weight_beams(v, home, wf, K, tid, st_prev);
     }
     __syncthreads();
     if (tid < K) {
@@ -298,6 +352,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
             v.upd_pose[p] = mean0; v.upd_pose[v.P + p] = mean1; v.upd_pose[2 * v.P + p] = mean2;   // robot.py:115
         }
     }
+    PSTAMP(4);
 }
 
 // rbpf_weight_samples (test entry for a4): explicit sample poses and motion probabilities, the PRODUCT's look-ups.  The
@@ -309,7 +364,12 @@ __global__ __launch_bounds__(BLOCK) void weight_samples_product_kernel(DevView v
     __shared__ float4 s_q[KMAX];
     __shared__ int s_tab[49];
     __shared__ unsigned long long s_base[49];
+    __shared__ int s_nredo[2];
+    __shared__ uint32_t s_redo[REDO_CAP];
+    __shared__ __align__(16) float s_bx[WB_CAP], s_by[WB_CAP];
     const int p = blockIdx.x, tid = threadIdx.x;
+    long long st_prev = clock64();
+    if (tid == 0) { s_nredo[0] = 0; s_nredo[1] = 0; }
     const int LL = v.L * v.L;
     const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
     for (int i = tid; i < LL; i += BLOCK) {
@@ -331,8 +391,8 @@ __global__ __launch_bounds__(BLOCK) void weight_samples_product_kernel(DevView v
     }
     __syncthreads();
     {
-        const WeightFrame wf{s_c, s_s, s_g, s_q, s_sum, s_tab, s_base};
-        weight_beams(v, home, wf, K, tid);
+        const WeightFrame wf{s_c, s_s, s_g, s_q, s_sum, s_tab, s_base, s_redo, s_nredo, s_bx, s_by};
+        weight_beams(v, home, wf, K, tid, st_prev);
     }
     __syncthreads();
     if (tid < K) {

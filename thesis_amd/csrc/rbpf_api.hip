@@ -222,12 +222,15 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         ALLOC(h, v.tile_bbox, (size_t)v.pool_tiles * 4); ALLOC(h, v.free_stack, v.pool_tiles); ALLOC(h, v.free_top, 1);
         {   // the scan block: one device buffer, uploaded with one copy per scan (rbpf_set_scan)
             const size_t MB = (size_t)c.max_beams, MBP = (MB + 15) & ~(size_t)15;
-            h->scan_bytes = 3 * MBP * 8 + 4 * MBP * 4 + MBP;
+            const size_t MBW = (MB + 63) & ~(size_t)63;           // the weighting's list is padded to whole passes of 64 beams
+            h->scan_bytes = 3 * MBP * 8 + 4 * MBP * 4 + MBP + 2 * MBW * 4 + MBW * 2;
             ALLOC(h, h->d_scan, h->scan_bytes);
             unsigned char* d = h->d_scan;
             v.bx = reinterpret_cast<double*>(d); v.by = v.bx + MBP; v.bscale = v.by + MBP;
             v.msel_x = reinterpret_cast<float*>(d + 3 * MBP * 8); v.msel_y = v.msel_x + MBP; v.asel_x = v.msel_y + MBP; v.asel_y = v.asel_x + MBP;
             v.bflags = d + 3 * MBP * 8 + 4 * MBP * 4;
+            v.wsel_x = reinterpret_cast<const float*>(d + 3 * MBP * 8 + 4 * MBP * 4 + MBP); v.wsel_y = v.wsel_x + MBW;
+            v.wsel_idx = reinterpret_cast<const uint16_t*>(v.wsel_y + MBW);
             rbpf_handle::PinnedRing* rings[3] = {&h->ring_scan, &h->ring_last, &h->ring_idx};
             const size_t bytes[3] = {h->scan_bytes, MB * 16, (size_t)P * 8};
             for (int r = 0; r < 3; ++r) {
@@ -464,7 +467,11 @@ static int upload_scan_points(rbpf_handle* h, const double* px, const double* py
     float* mx = reinterpret_cast<float*>(slot + 3 * MBP * 8);               // compacted beam lists for the matcher
     float* my = mx + MBP; float* ax = my + MBP; float* ay = ax + MBP;       // (float32, sensor frame)
     uint8_t* fl = slot + 3 * MBP * 8 + 4 * MBP * 4;
-    int nm = 0, na = 0;
+    const size_t MBW = ((size_t)c.max_beams + 63) & ~(size_t)63;
+    float* wx = reinterpret_cast<float*>(fl + MBP); float* wy = wx + MBW;   // the weighting's beams (kernels_propose.hip, weight_beams)
+    uint16_t* wi = reinterpret_cast<uint16_t*>(wy + MBW);
+    const float w_inv_cs = (float)((double)h->v.dim / h->v.tile_len), w_lim = 1.5f * (float)h->v.dim;
+    int nm = 0, na = 0, nw = 0;
     for (int i = 0; i < B; ++i) {
         const double x = px[i], y = py[i];
         double dist = sqrt(x * x + y * y);               // robot.py:129, hybridmap.py:105,217
@@ -477,9 +484,15 @@ static int upload_scan_points(rbpf_handle* h, const double* px, const double* py
         sx[i] = x; sy[i] = y; sc[i] = s; fl[i] = f;
         if (f & BF_MATCH) { mx[nm] = (float)x; my[nm] = (float)y; ++nm; }
         if (f & BF_MATCH_ADJ) { ax[na] = (float)x; ay[na] = (float)y; ++na; }
+        if (f & BF_WEIGHT) {
+            const float x32 = (float)x, y32 = (float)y;
+            const bool in_budget = h->v.dim <= 2048 && (fabsf(x32) + fabsf(y32)) * w_inv_cs <= w_lim;   // the error budget's premise
+            wx[nw] = in_budget ? x32 : NAN; wy[nw] = y32; wi[nw] = (uint16_t)i; ++nw;
+        }
     }
+    for (int i = nw; i < ((nw + 63) & ~63); ++i) { wx[i] = NAN; wy[i] = 0.0f; wi[i] = 0; }
     DevView& v = h->v;
-    v.n_msel = nm; v.n_asel = na;
+    v.n_msel = nm; v.n_asel = na; v.n_wsel = nw;
     {   // pinned and device-mapped: a kernel pulls the block over (no copy-engine latency in the stream); DMA otherwise
         void* mapped = nullptr;
         if (hipHostGetDevicePointer(&mapped, slot, 0) == hipSuccess && mapped) launch_ingest(mapped, h->d_scan, h->scan_bytes, h->stream);

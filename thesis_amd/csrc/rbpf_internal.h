@@ -66,6 +66,8 @@ struct DevView {
     const uint8_t* bflags;             // [B]
     float *msel_x, *msel_y; int n_msel;  // beams with BF_MATCH, compacted (metres, sensor frame)
     float *asel_x, *asel_y; int n_asel;  // beams with BF_MATCH_ADJ, compacted
+    const float *wsel_x, *wsel_y; const uint16_t* wsel_idx; int n_wsel;   // beams with BF_WEIGHT, compacted, single precision (x = NaN: outside
+                                         // the fast look-up's error budget), padded with NaN to a multiple of 64; their beam numbers
     // per-update scratch
     double*  upd_pose;                 // [3][P] poses used by the current map update
     double*  prop_prep;                // [P][24] proposal frame of the current scan update (kernels_propose.hip: U, A, mean, log c)
