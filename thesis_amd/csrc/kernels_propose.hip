@@ -124,6 +124,43 @@ __global__ __launch_bounds__(64) void propose_prep_kernel(DevView v, ProposeArgs
     o[21] = -0.5 * ((double)rank * 1.8378770664093453 + log_pdet);   // log(2*pi)
 }
 
+// ---- the K samples of every particle (robot.py:80-87): one thread per (particle, sample) - the normal deviates, the
+//      sample pose, its motion probability, the sine and cosine of its heading and its single-precision frame in home-tile cell
+//      coordinates.  (In the weighting kernel these few hundred float64 instructions were a serial prologue of 30 lanes.)
+static const int SAMP_W = 256;      // doubles per particle: cos[32], sin[32], x[32], y[32], theta[32], motion pdf[32], float4 frame[32]
+__global__ __launch_bounds__(256) void propose_samples_kernel(DevView v, ProposeArgs a) {
+    const int gid = blockIdx.x * 256 + threadIdx.x, p = gid >> 5, k = gid & 31, K = v.K;
+    if (p >= v.P || k >= K) return;
+    const double* pr = v.prop_prep + (size_t)p * PREP_W;
+    if (pr[22] != 0.0) return;                                       // robot.py:73-78: no proposal for this particle
+    const double mean[3] = {pr[18], pr[19], pr[20]};
+    double g[3];
+    if (a.guesses) {
+        const double* gp = a.guesses + ((size_t)p * K + k) * 3;
+        g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+    } else {
+        double z[3];
+        normals3(a.seed, a.stream, (uint32_t)v.global_id[p], (uint32_t)k, z);
+        for (int i = 0; i < 3; ++i) g[i] = mean[i] + ((pr[9 + 3 * i] * z[0] + pr[9 + 3 * i + 1] * z[1]) + pr[9 + 3 * i + 2] * z[2]);
+    }
+    // robot.py:87: pdf = exp(-0.5 * (rank*log(2pi) + log_pdet + maha)) * 10
+    const double d0 = g[0] - mean[0], d1 = g[1] - mean[1], d2 = g[2] - mean[2];
+    double maha = 0.0;
+    for (int j = 0; j < 3; ++j) { double t = (d0 * pr[j] + d1 * pr[3 + j]) + d2 * pr[6 + j]; maha += t * t; }
+    double sn, cs;
+    sincos(g[2], &sn, &cs);
+    // the home tile's offsets (home_tile(): the tile that holds the matcher's pose; without one the frame is not used)
+    int lx, ly, off_x = 0, off_y = 0;
+    if (!(v.dim & 1) && tile_of_coord(mean[0], v.tile_len, v.R, lx) && tile_of_coord(mean[1], v.tile_len, v.R, ly)) {
+        off_x = v.dim / 2 - lx * v.dim; off_y = v.dim / 2 - ly * v.dim;
+    }
+    const double inv_cs = (double)v.dim / v.tile_len;
+    double* o = v.prop_samp + (size_t)p * SAMP_W;
+    o[k] = cs; o[32 + k] = sn; o[64 + k] = g[0]; o[96 + k] = g[1]; o[128 + k] = g[2];
+    o[160 + k] = exp(pr[21] - 0.5 * maha) * 10;
+    reinterpret_cast<float4*>(o + 192)[k] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(g[0] * inv_cs + (double)off_x), (float)(g[1] * inv_cs + (double)off_y));
+}
+
 // ---- weighting: K gathers per beam (robot.py:118-139).  The samples of a beam end on neighbouring cells (one or two cache
 //      lines), so a beam's K look-ups are done together, eight at a time: eight cell addresses in the particle's home tile
 //      are formed without a branch, the eight byte loads are issued back to back, then added - nothing waits on a single
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     __shared__ float4 s_q[KMAX];                       // single-precision sample frame in home-tile cells: (cos, sin) / cell, offset x, y
     __shared__ int s_tab[49];
     __shared__ unsigned long long s_base[49];          // byte offset of each lattice tile in the pool, ~0 = none
-    __shared__ double s_U[3][3], s_A[3][3], s_mean[3], s_logc;
+    __shared__ double s_mean[3];
     __shared__ double s_mom[16];                       // moments: mean[3], norm, sig[9], min_w
     __shared__ int s_bad, s_nredo[2];
     __shared__ uint32_t s_redo[REDO_CAP];
@@ -268,9 +305,8 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
     const int LL = v.L * v.L;
     {   // the frame propose_prep_kernel left
         const double* pr = v.prop_prep + (size_t)p * PREP_W;
-        if (tid < 9) { s_U[tid / 3][tid % 3] = pr[tid]; s_A[tid / 3][tid % 3] = pr[9 + tid]; }
         if (tid < 3) s_mean[tid] = pr[18 + tid];
-        if (tid == 0) { s_logc = pr[21]; s_bad = pr[22] != 0.0; }
+        if (tid == 0) s_bad = pr[22] != 0.0;
     }
     const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
     for (int i = tid; i < LL; i += BLOCK) {
@@ -284,26 +320,11 @@ __global__ __launch_bounds__(BLOCK) void propose_weight_kernel(DevView v, Propos
         return;
     }
     const HomeTile home = home_tile(v, s_tab, s_mean[0], s_mean[1]);
-    const double inv_cs = (double)v.dim / v.tile_len;
-    if (tid < K) {
-        double g[3];
-        if (a.guesses) {
-            const double* gp = a.guesses + ((size_t)p * K + tid) * 3;
-            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
-        } else {
-            double z[3];
-            normals3(a.seed, a.stream, (uint32_t)v.global_id[p], (uint32_t)tid, z);
-            for (int i = 0; i < 3; ++i) g[i] = s_mean[i] + ((s_A[i][0] * z[0] + s_A[i][1] * z[1]) + s_A[i][2] * z[2]);
-        }
-        // robot.py:87: pdf = exp(-0.5 * (rank*log(2pi) + log_pdet + maha)) * 10
-        double d0 = g[0] - s_mean[0], d1 = g[1] - s_mean[1], d2 = g[2] - s_mean[2];
-        double maha = 0.0;
-        for (int j = 0; j < 3; ++j) { double t = (d0 * s_U[0][j] + d1 * s_U[1][j]) + d2 * s_U[2][j]; maha += t * t; }
-        s_pr[tid] = exp(s_logc - 0.5 * maha) * 10;
-        double sn, cs;
-        sincos(g[2], &sn, &cs);
-        s_c[tid] = cs; s_s[tid] = sn; s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
-        s_q[tid] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(g[0] * inv_cs + (double)home.off_x), (float)(g[1] * inv_cs + (double)home.off_y));
+    if (tid < K) {                                                   // the samples propose_samples_kernel left
+        const double* sp = v.prop_samp + (size_t)p * SAMP_W;
+        s_c[tid] = sp[tid]; s_s[tid] = sp[32 + tid]; s_g[tid][0] = sp[64 + tid]; s_g[tid][1] = sp[96 + tid]; s_g[tid][2] = sp[128 + tid];
+        s_pr[tid] = sp[160 + tid];
+        s_q[tid] = reinterpret_cast<const float4*>(sp + 192)[tid];
         s_sum[tid] = 0;
     }
     __syncthreads();
@@ -415,6 +436,7 @@ void launch_propose_weight(const DevView& v, const double* d_match, const int32_
                            uint64_t seed, uint32_t stream, double* d_dbg_w, hipStream_t s) {
     ProposeArgs a{d_match, d_match_of, d_guesses, d_bad, seed, stream, d_dbg_w};
     hipLaunchKernelGGL(propose_prep_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, v, a);
+    hipLaunchKernelGGL(propose_samples_kernel, dim3((v.P * 32 + 255) / 256), dim3(256), 0, s, v, a);
     hipLaunchKernelGGL(propose_weight_kernel, dim3(v.P), dim3(BLOCK), 0, s, v, a);
 }
 void launch_bad_weight(const DevView& v, const uint8_t* d_bad, hipStream_t s) {

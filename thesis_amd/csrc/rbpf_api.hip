@@ -241,6 +241,7 @@ int rbpf_create(const rbpf_config* cfg, rbpf_handle** out) {
         }
         ALLOC(h, v.upd_pose, 3 * P);
         ALLOC(h, v.prop_prep, 24 * P);
+        ALLOC(h, v.prop_samp, 256 * P);
         ALLOC(h, v.stats, ST_COUNT); ALLOC(h, v.err, 1);
         ALLOC(h, v.mu_fallback, P); HIP_TRY(h, hipMemset(v.mu_fallback, 0, P * 4));
         ALLOC(h, h->d_did_early, 1);

@@ -71,6 +71,7 @@ struct DevView {
     // per-update scratch
     double*  upd_pose;                 // [3][P] poses used by the current map update
     double*  prop_prep;                // [P][24] proposal frame of the current scan update (kernels_propose.hip: U, A, mean, log c)
+    double*  prop_samp;                // [P][256] its K samples: cos, sin, pose, motion probability, single-precision frame
     int32_t* mu_fallback;              // [P] != 0: the map-update kernel that ran first gave the particle back to the next one
     int mu_mode;                       // 0 = event-walk kernel (kernels_mapev.hip; the global-index kernel of round 2, kernels_mapray.hip, where
                                        // that one is not available: more than 1536 beams), then 128x128 windows for what it gave back;
