@@ -241,6 +241,9 @@ __device__ __forceinline__ void weight_beams(const DevView& v, const HomeTile& h
                     // (bit-wise &: the conditions are cheap, a short-circuit would be a branch per look-up)
                     fast[u] = ((int)(fminf(rx, ry) > WSAFE) & (int)(fmaxf(rx, ry) < 1.0f - WSAFE) & (int)(max((unsigned)ix, (unsigned)iy) < (unsigned)v.dim)) != 0;
                     addr[u] = fast[u] ? __umul24((uint32_t)ix, (uint32_t)v.dim) + (uint32_t)iy : 0u;
+#ifdef WEIGHT_ABLATE_ADDR
+                    addr[u] &= 63u;                 // diagnostic build: every look-up falls into one cache line
+#endif
                     redo |= fast[u] ? 0u : 1u << u;
                 }
             }
