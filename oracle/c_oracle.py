@@ -42,8 +42,8 @@ def ldp(a):
 
 
 class CMap:
-    def __init__(self, lib, cs=0.05):
-        self.lib, self.h = lib, lib.orc_map_new(cs, 40)
+    def __init__(self, lib, cs=0.05, tile_len=40):
+        self.lib, self.h = lib, lib.orc_map_new(cs, tile_len)
         self.dim = lib.orc_map_dim(self.h)
 
     def __del__(self):

@@ -20,10 +20,10 @@ def _wsafe(dim):
     return 1e-3 if dim <= 1024 else 2e-3
 
 
-def _build(eng_mod, lib, cs, P, B, rng, centres):
+def _build(eng_mod, lib, cs, P, B, rng, centres, **engine_options):
     """An engine and one C-oracle map per particle with the same dense random tiles."""
-    e = eng_mod.ParticleEngine(P, max_beams=B, cell_size=cs, pool_tiles=P * (len(centres) + 1) + 2)
-    maps = [c_oracle.CMap(lib, cs) for _ in range(P)]
+    e = eng_mod.ParticleEngine(P, max_beams=B, cell_size=cs, pool_tiles=P * (len(centres) + 1) + 2, **engine_options)
+    maps = [c_oracle.CMap(lib, cs, **({"tile_len": engine_options["tile_len_m"]} if "tile_len_m" in engine_options else {})) for _ in range(P)]
     for p in range(P):
         for (cx, cy) in centres:
             cells = rng.integers(-30, 31, size=(e.dim, e.dim)).astype(np.int8)
@@ -110,6 +110,52 @@ def test_product_lookups_on_the_home_tile_rim_and_beyond():
     far = np.asarray(pose[:2]) + np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
     pts = np.vstack([near, far])
     sx, sy = _sensor_frame(pts, pose)
+    e.set_scan_xy(sx, sy)
+    g = _guesses(rng, pose, cs, K, P)
+    prs = rng.uniform(0.5, 2.0, size=(P, K))
+    assert _check(e, maps, g, sx, sy, prs) < 1e-12
+    e.close()
+
+
+def test_product_lookups_with_more_beams_than_one_lds_chunk():
+    """2000 beams: the kernel stages the beams that count in chunks of 1536 (two chunks, the second one partly padding);
+    every fifth beam is outside the weighting's range (robot.py:130) and is not in the list at all."""
+    from thesis_amd import engine as eng_mod
+    lib = c_oracle.load()
+    rng = np.random.Generator(np.random.PCG64(2000))
+    cs, P, B, K = 0.05, 2, 2000, 30
+    e, maps = _build(eng_mod, lib, cs, P, B, rng, [(0, 0)])
+    pose = (rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-np.pi, np.pi))
+    pts = _border_points(rng, cs, e.dim, B, pose[:2], int(6.0 / cs))
+    ang = rng.uniform(-np.pi, np.pi, size=B // 5)
+    pts[::5] = np.asarray(pose[:2]) + 30.0 * np.column_stack([np.cos(ang), np.sin(ang)])      # beyond weight_max_range (25 m)
+    sx, sy = _sensor_frame(pts, pose)
+    e.set_scan_xy(sx, sy)
+    g = _guesses(rng, pose, cs, K, P)
+    prs = rng.uniform(0.5, 2.0, size=(P, K))
+    assert _check(e, maps, g, sx, sy, prs) < 1e-12
+    e.close()
+
+
+def test_product_lookups_with_beams_outside_the_error_budget():
+    """8 m tiles (dim 160): a beam whose |x| + |y| exceeds 1.5 tile lengths is outside the premise of the single-precision
+    addresses - the host stores it as NaN in the weighting's beam list and every one of its look-ups goes the float64 way
+    (more of them than the queue holds: the rest are done on the spot).  Nine tiles round the pose, end points up to 24 m away."""
+    from thesis_amd import engine as eng_mod
+    lib = c_oracle.load()
+    rng = np.random.Generator(np.random.PCG64(10))
+    cs, P, B, K = 0.05, 2, 1081, 30
+    centres = [(8 * i, 8 * j) for i in (-1, 0, 1) for j in (-1, 0, 1)]
+    e, maps = _build(eng_mod, lib, cs, P, B, rng, centres, tile_len_m=8, max_ray_m=7.0)   # (rays must be shorter than a tile: the map update is not run here)
+    assert e.dim == 160
+    pose = (rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-np.pi, np.pi))
+    near = _border_points(rng, cs, e.dim, 500, pose[:2], int(3.0 / cs))
+    ang = rng.uniform(-np.pi, np.pi, size=B - 500)
+    rad = rng.uniform(4.0, 24.0, size=B - 500)
+    far = np.asarray(pose[:2]) + np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
+    pts = np.vstack([near, far])
+    sx, sy = _sensor_frame(pts, pose)
+    assert np.sum(np.abs(sx) + np.abs(sy) > 12.0) > 100            # beams outside the budget exist
     e.set_scan_xy(sx, sy)
     g = _guesses(rng, pose, cs, K, P)
     prs = rng.uniform(0.5, 2.0, size=(P, K))
