@@ -242,6 +242,7 @@ struct CopyArgs {
     DevView v;
     const int32_t* jobs; int32_t* n_jobs;     // n_jobs[0] = jobs, n_jobs[1] = queue head
     int32_t* pending_free; int32_t* n_pending;
+    int gather; GatherArgs ga;                // the state permutation rides along (a thread per particle before the tile jobs)
 };
 
 template <int NT>
@@ -295,6 +296,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void resample_copy_kernel(CopyArgs a) {
     const int tid = threadIdx.x;
     const int LL = v.L * v.L;
     const size_t cells = (size_t)v.dim * v.dim;
+    if (a.gather)
+        for (int j = blockIdx.x * COPY_BLOCK + tid; j < a.ga.P; j += gridDim.x * COPY_BLOCK) resample_gather_one(a.ga, j);
     // a workgroup's first job is its own index; only the jobs beyond the grid go through the queue head (one returning atomic
     // on one address per workgroup and job is a chain of L2 round trips that 512 workgroups would stand in line for)
     for (int round = 0;; ++round) {
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void sources_to_T_kernel(int P, const
 // three kernel launches and their dispatch gaps per resample.
 enum { RS_PLAN = 1, RS_SRC2T = 2, RS_EXPAND = 4, RS_PAIR = 8, RS_GATHER = 16 };
 static const int RS_FUSE_MAX = 4096;        // beyond this the single workgroup costs more than the launches it saves
+static const int RS_GATHER_FUSE_MAX = 1024; // ... and the state permutation alone beyond this
 struct FusedArgs { int stages; ResampleArgs ra; int32_t* idx; PairArgs pa; GatherArgs ga; };
 __global__ __launch_bounds__(PLAN_THREADS) void resample_fused_kernel(FusedArgs f) {
     // T and the ancestor indices also live in LDS from the stage that makes them: the later stages search and chase them
@@ -535,15 +539,28 @@ __global__ __launch_bounds__(PLAN_THREADS) void resample_fused_kernel(FusedArgs 
     extern __shared__ __align__(16) int32_t s_dyn[];                       // 2 * RS_FUSE_MAX words (dynamic: the stages' own arrays fill the static 64 KB)
     int32_t* const s_T = s_dyn; int32_t* const s_idx = s_dyn + RS_FUSE_MAX;
     const int tid = threadIdx.x, P = f.ra.P;
+#ifdef RBPF_STAMPS
+    long long st[6]; st[0] = clock64();
+#define RSTAMP(k) st[k] = clock64()
+#else
+#define RSTAMP(k) do { } while (0)
+#endif
     if (f.stages & RS_PLAN) { resample_plan_stage(f.ra); __syncthreads(); }
+    RSTAMP(1);
     if (f.stages & RS_SRC2T) { sources_to_T_stage(P, f.idx, f.ra.T, f.ra.did); __syncthreads(); }
     for (int j = tid; j < P; j += PLAN_THREADS) s_T[j] = f.ra.T[j];
     __syncthreads();
     if (f.stages & RS_EXPAND) { for (int j = tid; j < P; j += PLAN_THREADS) { resample_expand_one(P, s_T, s_idx, j); f.idx[j] = s_idx[j]; } }
     else for (int j = tid; j < P; j += PLAN_THREADS) s_idx[j] = f.idx[j];
     __syncthreads();
+    RSTAMP(2);
     if (f.stages & RS_PAIR) { PairArgs pa = f.pa; pa.T = s_T; pa.idx = s_idx; resample_pair_stage(pa); __syncthreads(); }
+    RSTAMP(3);
     if (f.stages & RS_GATHER) { GatherArgs ga = f.ga; ga.T = s_T; ga.idx = s_idx; for (int j = tid; j < ga.P; j += PLAN_THREADS) resample_gather_one(ga, j); }
+    RSTAMP(4);
+#ifdef RBPF_STAMPS
+    if (tid == 0) printf("resample_fused: plan %lld expand %lld pair %lld gather %lld cycles\n", st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
+#endif
 }
 
 static void launch_resample_fused(const FusedArgs& f, hipStream_t s) {
@@ -593,11 +610,14 @@ void launch_resample_local(const DevView& v, const ResampleBuffers& b, const dou
         launch_resample_apply(v, b, s);
         return;
     }
-    FusedArgs f{RS_PLAN | RS_EXPAND | RS_PAIR | RS_GATHER, ResampleArgs{v.P, d_w, u, spread, b.T, b.did, v.err}, b.idx,
-                PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
-                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of}};
+    // the state permutation moves 200 bytes per particle: through one CU it took as long as the three planning stages together
+    // (25 us of the fused kernel's 54 at 4096 particles), so beyond RS_GATHER_FUSE_MAX particles it is a launch of its own
+    const bool fuse_gather = v.P <= RS_GATHER_FUSE_MAX;
+    const GatherArgs ga{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of};
+    FusedArgs f{RS_PLAN | RS_EXPAND | RS_PAIR | (fuse_gather ? RS_GATHER : 0), ResampleArgs{v.P, d_w, u, spread, b.T, b.did, v.err}, b.idx,
+                PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err}, ga};
     launch_resample_fused(f, s);
-    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
+    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending, fuse_gather ? 0 : 1, ga};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
@@ -609,11 +629,12 @@ void launch_resample_apply_sources(const DevView& v, const ResampleBuffers& b, h
         launch_resample_apply(v, b, s);
         return;
     }
-    FusedArgs f{RS_SRC2T | RS_PAIR | RS_GATHER, ResampleArgs{v.P, nullptr, 0.0, 0.0, b.T, b.did, v.err}, b.idx,
-                PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err},
-                GatherArgs{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of}};
+    const bool fuse_gather = v.P <= RS_GATHER_FUSE_MAX;
+    const GatherArgs ga{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight, b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of};
+    FusedArgs f{RS_SRC2T | RS_PAIR | (fuse_gather ? RS_GATHER : 0), ResampleArgs{v.P, nullptr, 0.0, 0.0, b.T, b.did, v.err}, b.idx,
+                PairArgs{v.P, b.T, b.idx, b.did, v.slot, b.slot2, b.dead_list, b.jobs, b.n_jobs, v.err}, ga};
     launch_resample_fused(f, s);
-    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
+    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending, fuse_gather ? 0 : 1, ga};
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
@@ -623,8 +644,7 @@ void launch_resample_apply(const DevView& v, const ResampleBuffers& b, hipStream
     hipLaunchKernelGGL(resample_pair_kernel, dim3(1), dim3(PLAN_THREADS), 0, s, pa);
     GatherArgs ga{v.P, b.idx, b.did, v.px, v.py, v.pth, v.cov, v.weight,
                   b.px2, b.py2, b.pth2, b.cov2, b.w2, b.T, v.dup_of};
-    hipLaunchKernelGGL(resample_gather_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, ga);
-    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending};
+    CopyArgs ca{v, b.jobs, b.n_jobs, b.pending_free, b.n_pending, 1, ga};          // (the state permutation rides with the tile copies)
     hipLaunchKernelGGL(resample_copy_kernel, dim3(512), dim3(COPY_BLOCK), 0, s, ca);
     hipLaunchKernelGGL(resample_release_kernel, dim3(1), dim3(256), 0, s, v, b.pending_free, b.n_pending);
 }
