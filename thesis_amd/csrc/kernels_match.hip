@@ -116,6 +116,21 @@ size_t match_lds_bytes(int N, int B, int n_coarse, int per_rot) {
 }
 int match_sc_capacity(int N, int B, size_t lds) { return (int)((lds - match_lds_base(N, B)) / 4); }
 
+// lane i takes lane i + N of its row of 16 lanes (0 where there is none): the last four steps of a wave sum that ends in lane 0
+// with the additions paired as __shfl_down pairs them, through the data-parallel-primitive path
+template <int N>
+__device__ __forceinline__ double dpp_row_shl_f64(double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x100 + N, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x100 + N, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double wave_sum_lane0_f64(double x) {
+    x += __shfl_down(x, 32, 64); x += __shfl_down(x, 16, 64);
+    x += dpp_row_shl_f64<8>(x); x += dpp_row_shl_f64<4>(x); x += dpp_row_shl_f64<2>(x); x += dpp_row_shl_f64<1>(x);
+    return x;
+}
+
 __device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w) {
     if ((unsigned)u >= (unsigned)N || (unsigned)w >= (unsigned)N) return 0;
     int idx = u * (N >> 5) + (w >> 5);
@@ -648,9 +663,9 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
             m[0] += w; m[1] += w * ex; m[2] += w * ey; m[3] += w * et;
             m[4] += w * ex * ex; m[5] += w * ex * ey; m[6] += w * ex * et; m[7] += w * ey * ey; m[8] += w * ey * et; m[9] += w * et * et;
         }
+#pragma unroll
         for (int k = 0; k < 10; ++k) {                    // fixed-order reduction: results must not depend on wave timing
-            double x = m[k];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            const double x = wave_sum_lane0_f64(m[k]);
             if ((tid & 63) == 0) s_wmom[tid >> 6][k] = x;
         }
     }
