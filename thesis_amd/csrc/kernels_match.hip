@@ -138,13 +138,14 @@ __device__ __forceinline__ int field_hit(const MatchLds& s, int N, int u, int w)
     return ((s.occ[idx] & m) ? 1 : 0) + ((s.dil[idx] & m) ? 1 : 0);
 }
 // guess, search window (robot.py:62-65) and region origin of one match problem
-__device__ inline void match_frame(const DevView& v, const MatchArgs& a, int p, double* g, double* rng, int* org) {
+// pose5 = the particle's x, y, theta, cov[0][0], cov[1][1] (not looked at by the stateless twin)
+__device__ inline void match_frame_from(const MatchArgs& a, const double* pose5, double* g, double* rng, int* org) {
     double gx, gy, gth, rx, ry;
     if (a.single) {
         gx = a.guess[0]; gy = a.guess[1]; gth = a.guess[2]; rx = a.range[0]; ry = a.range[1];
     } else {
-        gx = v.px[p]; gy = v.py[p]; gth = v.pth[p];
-        double c00 = v.cov[(size_t)0 * v.P + p], c11 = v.cov[(size_t)4 * v.P + p];
+        gx = pose5[0]; gy = pose5[1]; gth = pose5[2];
+        double c00 = pose5[3], c11 = pose5[4];
         double p0 = sqrt(c00) * 30.0, p1 = sqrt(c11) * 30.0;                 // robot.py:62
         ry = fmax(fmin(4 * p1, 0.7), 0.1);                                   // robot.py:64
         rx = fmax(fmin(4 * p0, 0.7), 0.1);                                   // robot.py:65
@@ -154,12 +155,23 @@ __device__ inline void match_frame(const DevView& v, const MatchArgs& a, int p, 
     org[1] = (int)floor(gy / a.mcs) - a.N / 2;
 }
 
+__device__ inline void match_frame(const DevView& v, const MatchArgs& a, int p, double* g, double* rng, int* org) {
+    double pose5[5] = {0, 0, 0, 0, 0};
+    if (!a.single) { pose5[0] = v.px[p]; pose5[1] = v.py[p]; pose5[2] = v.pth[p]; pose5[3] = v.cov[p]; pose5[4] = v.cov[(size_t)4 * v.P + p]; }
+    match_frame_from(a, pose5, g, rng, org);
+}
+
 __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, W = N >> 5, tid = threadIdx.x, p = blockIdx.x;
     // An exact duplicate (a copy made by the last resample: same pose, covariance and map) would repeat its
     // representative's search bit for bit; the proposal kernel reads the representative's row instead.
-    if (a.dup_of && a.dup_of[p] != p) { if (tid == 0) atomicAdd(&v.stats[ST_MATCH_SHARED], 1ull); return; }
+    // (the loads the set-up needs are issued together with the duplicate test's: one round trip to memory instead of three)
+    const int dup = a.dup_of ? a.dup_of[p] : p;
+    double pre[5] = {0, 0, 0, 0, 0}; int pre_slot = 0;
+    if (!a.single && tid == 0) { pre[0] = v.px[p]; pre[1] = v.py[p]; pre[2] = v.pth[p]; pre[3] = v.cov[p]; pre[4] = v.cov[(size_t)4 * v.P + p]; }
+    if (!a.single) pre_slot = v.slot[p];
+    if (dup != p) { if (tid == 0) atomicAdd(&v.stats[ST_MATCH_SHARED], 1ull); return; }
     MatchLds s;
     s.occ = reinterpret_cast<uint32_t*>(smem);
     s.dil = s.occ + (size_t)N * W;
@@ -179,12 +191,12 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
 #endif
     // ---- guess, search window (robot.py:62-65), region origin ----------------------------------------------
     if (tid == 0) {
-        match_frame(v, a, p, s_g, s_rng, s_org);
+        match_frame_from(a, pre, s_g, s_rng, s_org);
         s_nb = 0; s_best = INT_MIN; s_bestc = 0; s_slowg = 0;
         for (int i = 0; i < 10; ++i) s_mom[i] = 0.0;
     }
     if (!a.single) {
-        const int32_t* tab = v.tile_tab + (size_t)v.slot[p] * v.L * v.L;
+        const int32_t* tab = v.tile_tab + (size_t)pre_slot * v.L * v.L;
         for (int i = tid; i < v.L * v.L; i += MBLOCK) s_tab[i] = tab[i];
     }
     // the occupancy words are OR-ed into when rasterised from points (mode 1); every other word of the three fields is
@@ -348,12 +360,20 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         __syncthreads();                                        // colmap memory is the score table again below
     } else {
         // occupancy rasterised from reference points (previous accepted scan, hybridmap.py:167-171)
-        for (int i = tid; i < a.n_ref; i += MBLOCK) {
-            double rx = a.ref_xy[2 * i], ry = a.ref_xy[2 * i + 1];
+        const int RP = 4;                                       // points per thread in flight
+        for (int i0 = tid; i0 < a.n_ref; i0 += RP * MBLOCK) {
+          double2 pt[RP];
+#pragma unroll
+          for (int k = 0; k < RP; ++k) { const int i = i0 + k * MBLOCK; pt[k] = i < a.n_ref ? reinterpret_cast<const double2*>(a.ref_xy)[i] : make_double2(0.0, 0.0); }
+#pragma unroll
+          for (int k = 0; k < RP; ++k) {
+            if (i0 + k * MBLOCK >= a.n_ref) continue;
+            double rx = pt[k].x, ry = pt[k].y;
             double dx = rx - s_g[0], dy = ry - s_g[1];
             if (!(sqrt(dx * dx + dy * dy) < a.max_range)) continue;   // hybridmap.py:171 (11 m); matchScanCustom.m:11 (15 m)
             int u = (int)floor(rx / a.mcs + a.cell_off) - ox, w = (int)floor(ry / a.mcs + a.cell_off) - oy;
             if ((unsigned)u < (unsigned)N && (unsigned)w < (unsigned)N) atomicOr(&s.occ[u * W + (w >> 5)], 1u << (w & 31));
+          }
         }
     }
     // selected beams (in matcher-cell units, sensor frame)
@@ -375,11 +395,21 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
     {
         const int nchunk = max(1, MBLOCK / W), rows_per = (N + nchunk - 1) / nchunk;
         const int wv = tid % W, chunk = tid / W;
+        // (sixteen words per row: the lanes of a DPP row hold one field row, and a word's neighbours come from the lanes beside
+        // it - 0 at the row's ends - instead of two more LDS reads)
+        const bool row16 = W == 16;
         auto hdil = [&](int u) -> uint32_t {
-            if (u < 0 || u >= N) return 0u;
-            const uint32_t c = s.occ[u * W + wv];
-            const uint32_t l = wv > 0 ? s.occ[u * W + wv - 1] : 0u, r = wv + 1 < W ? s.occ[u * W + wv + 1] : 0u;
-            return c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+            const bool inr = u >= 0 && u < N;
+            const uint32_t c = inr ? s.occ[u * W + wv] : 0u;
+            uint32_t lb, rb;
+            if (row16) {
+                lb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(c >> 31), 0x111, 0xF, 0xF, true);     // row_shr:1: bit 31 of the word before
+                rb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(c << 31), 0x101, 0xF, 0xF, true);     // row_shl:1: bit 0 of the word after
+            } else {
+                lb = (inr && wv > 0) ? s.occ[u * W + wv - 1] >> 31 : 0u;
+                rb = (inr && wv + 1 < W) ? s.occ[u * W + wv + 1] << 31 : 0u;
+            }
+            return c | (c << 1) | (c >> 1) | lb | rb;
         };
         if (chunk < nchunk) {
             const int u0 = chunk * rows_per, u1 = min(N, u0 + rows_per);
