@@ -218,7 +218,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     __shared__ int s_fan[4];
     __shared__ int s_wsum[EB / 64], s_wsum2[EB / 64];
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
-    __shared__ int s_nev, s_written;
+    __shared__ int s_nev, s_written, s_wbq;
     __shared__ unsigned long long s_cells;
     __shared__ double s_sincos[2];
     __shared__ uint8_t s_ggf[192];                    // per (tile column, 32-column group): a glitched column among its 33
@@ -752,6 +752,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             const uint32_t f = ((mini[mi >> 1] >> ((mi & 1) * 16)) & 0xFFFFu) >> 1;
             if (f) cnt8[row * stride + col] = (uint8_t)(min(f, (uint32_t)sat) << 1);
         }
+        if (tid == 0) s_wbq = 0;
         BAR_LDS();
         // ---- write-back: one read-modify-write per touched 32-cell group of storage cells, tile by tile.  Storage cell s
         //      receives global cell s - C where that one is not glitched plus global cell s - C + 1 where that one is.  The
@@ -762,6 +763,10 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             const EvWb wbk = {(uint32_t)(128 + v.cc.vmin) * 0x01010101u, (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u, satb, sadd, -v.cc.emp};
             const uint32_t kb1 = (uint32_t)(128 + v.cc.vmin) * 0x01010101u;             // byte-wise: (cell ^ 0x80) - kb1 = cell - vmin
             const uint32_t oadd = (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u; // bit 7 of (R + oadd) = cell > thr
+            // Waves draw batches of 64 items (32-cell groups) from a queue: the rows at the fan's rim hold few touched groups, and
+            // with a fixed share per wave the workgroup waited a quarter of the write-back's time for its slowest wave.
+            auto next_batch = [&]() -> int { int g = 0; if (lane == 0) g = atomicAdd(&s_wbq, 1); return UNI(g); };
+            int batch = next_batch(), batch0 = 0;                        // batch0: the first batch of the tile at hand
             for (int a = S0 / v.dim; a <= S1 / v.dim; ++a)
             for (int bt = T_lo / v.dim; bt <= T_hi / v.dim; ++bt) {
                 if (a >= v.L || bt >= v.L) continue;                                   // uniform
@@ -772,8 +777,12 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                 const int ngr = g_hi - g_lo + 1, items = (sr_hi - sr_lo + 1) * ngr;
                 int8_t* __restrict__ tile_base = v.pool + (size_t)tile * v.dim * v.dim;
                 int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
-                for (int it = tid; it < items; it += EB) {
-                    const int rr = it / ngr, gg = it - rr * ngr;
+                const int nbatch = (items + 63) >> 6;
+                const float inv_ngr = 1.0f / (float)ngr;
+                for (; batch < batch0 + nbatch; batch = next_batch()) {
+                    const int it = ((batch - batch0) << 6) + lane;
+                    if (it >= items) continue;
+                    const int rr = (int)(((float)it + 0.5f) * inv_ngr), gg = it - rr * ngr;   // it / ngr: (it + 0.5) / ngr is at least 0.5 / 192 from a whole number, the float product's error 1e-4 of that
                     const int srow = sr_lo + rr, gt = g_lo + gg;
                     const int ia = srow - C - fxl;                                     // source rows a (if not glitched), a + 1 (if glitched)
                     const bool va = !gxb[ia], vb = gxb[ia + 1];
@@ -896,6 +905,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                     v.occ[((size_t)tile * v.dim + row_t) * v.ow + gt] = occ;
                     bx0 = min(bx0, row_t); bx1 = max(bx1, row_t);
                 }
+                batch0 += nbatch;
                 bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
                 if (lane == 0 && bx1 >= 0) {                                           // this workgroup is the tile's only writer
                     atomicMin(&v.tile_bbox[4 * tile + 0], bx0); atomicMax(&v.tile_bbox[4 * tile + 1], bx1);
@@ -908,6 +918,9 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         STAMP(4);
     }
     BAR_LDS();                                                                // the window's LDS is free (the write-back's stores are still on their way)
+#ifdef EV_STAMP_SPLIT
+    STAMP(5);
+#endif
 
     // ======================================== flagged cells ========================================
     uint32_t* const keys = reinterpret_cast<uint32_t*>(smem + G.o_cnt + G.p_keys);    // [T] storage cell, ~0 = empty
@@ -932,11 +945,23 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         if (my_sc[i] == 0xFFFFFFFFu) continue;
         bool created;
         const int h = ev_hash_insert2(keys, T, G.logT, my_sc[i], created);
-        if (created) { rlist[atomicAdd(&s_wsum[1], 1)] = (uint16_t)h; oldc[h] = (int8_t)my_old[i]; }
+        {   // a record per new cell: the wave's new cells take their places in the record list with ONE add (1300 returning adds
+            // on one LDS word stand in line otherwise)
+            const unsigned long long mk = __ballot(created);
+            if (created) {
+                const int first = __ffsll((long long)mk) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&s_wsum[1], __popcll(mk));
+                base = __shfl(base, first, 64);
+                rlist[base + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)h; oldc[h] = (int8_t)my_old[i];
+            }
+        }
         nextp[tid + i * EB] = (uint16_t)atomicExch(&head[h], (uint32_t)(tid + i * EB));
     }
     BAR_LDS();
+#ifndef EV_STAMP_SPLIT
     STAMP(5);
+#endif
     if (!overflow) {
         // every listed pass is counted in front of the first event of a beam that is not smaller than its own (a beam's own
         // passes come before its own occupied / nearby hit), or behind the cell's last event
