@@ -28,6 +28,10 @@ namespace rbpf {
 
 #ifdef RBPF_STAMPS
 #define STAMP(k) do { if (tid == 0) { long long t_ = clock64(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
+#ifdef EV_BARRIER_WAITS      // diagnostic: cycles every wave spends at the workgroup's barriers (printed by workgroup 0)
+#undef BAR_LDS
+#define BAR_LDS() do { const long long t0_ = clock64(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); { const long long d_ = clock64() - t0_; bar_wait += d_; if (bar_n < 12) bar_w[bar_n] = (int)d_; } ++bar_n; } while (0)
+#endif
 #else
 #define STAMP(k) do { } while (0)
 #endif
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     __shared__ int s_fan[4];
     __shared__ int s_wsum[EB / 64], s_wsum2[EB / 64];
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
-    __shared__ int s_nev, s_written, s_wbq;
+    __shared__ int s_nev, s_written, s_wbq, s_walkq;
     __shared__ unsigned long long s_cells;
     __shared__ double s_sincos[2];
     __shared__ uint8_t s_ggf[192];                    // per (tile column, 32-column group): a glitched column among its 33
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     int32_t* tab = v.tile_tab + (size_t)v.slot[p] * LL;
 #ifdef RBPF_STAMPS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+    long long bar_wait = 0; int bar_n = 0; const long long t_begin = clock64(); int bar_w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // =============================================== setup ===============================================
     // this thread's beams: one per thread (two for the first few)
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
             uint4* c4 = reinterpret_cast<uint4*>(cnt);
             const int n16 = (rows_w * stride + 15) >> 4;
             for (int i = tid; i < n16; i += EB) c4[i] = make_uint4(0, 0, 0, 0);
+            if (tid == 0) s_walkq = 0;
         }
         BAR_LDS();
         // ---- flags: every global cell that maps to a storage cell with an occupied / nearby hit; the flag comes with a
@@ -711,35 +717,46 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
                 const int ii = lane * nwk + wslot;
                 if (ii < nk_c) { nb = perm[ii]; nfs = r_fs[nb]; nend = r_end[nb]; nka = (int)r_kl[nb] & 0xFF; }
             };
-            fetch_item(wave);
-            for (int q = wave; q < nitems; q += EB / 64) {
+            // Items are drawn from a queue, two ahead (the draw's answer arrives with the item's sixteen): with a fixed share per
+            // wave the oldest wave of every SIMD - the arbiter serves it first - waited a third of the walk for the youngest.
+            auto draw_begin = [&]() -> int { int g = 0; if (lane == 0) g = atomicAdd(&s_walkq, 1); return g; };
+            int q = UNI(draw_begin()), qn = UNI(draw_begin());
+            fetch_item(q);
+            while (q < nitems) {
                 const int b = nb; const uint32_t fs = nfs; const int32_t re = nend;
                 k = kn + nka - 1;                                                 // the ray's chunk at this relative level
-                if (b < 0) { fetch_item(q + EB / 64); continue; }
-                const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
-                const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
-                const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
-                const int cj = aey > aex ? sy1 : sxs, cm = aey > aex ? sxs : sy1;
                 const int j0 = NEAR_R + (k - 1) * LCH;
-                const unsigned long long pr64 = (unsigned long long)fs * (unsigned)j0 + 0x80000000ull;
-                uint32_t acc = (uint32_t)pr64, m = 0;
-                int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
-                const int d0 = cj, d1 = cj + cm;
                 uint32_t ret[LCH]; int sh[LCH];
+                if (b >= 0) {
+                    const int ex = (int)(int16_t)(re & 0xFFFF), ey = (int)(int16_t)((uint32_t)re >> 16);
+                    const int aex = ex < 0 ? -ex : ex, aey = ey < 0 ? -ey : ey;
+                    const int sxs = ex > 0 ? stride : -stride, sy1 = ey > 0 ? 1 : -1;
+                    const int cj = aey > aex ? sy1 : sxs, cm = aey > aex ? sxs : sy1;
+                    const unsigned long long pr64 = (unsigned long long)fs * (unsigned)j0 + 0x80000000ull;
+                    uint32_t acc = (uint32_t)pr64;
+                    int c = base0 + __mul24(j0, cj) + __mul24((int)(pr64 >> 32), cm);
+                    const int d0 = cj, d1 = cj + cm;
 #pragma unroll
-                for (int u = 0; u < LCH; ++u) {
-                    sh[u] = c << 3;
-                    ret[u] = ev_lds_add_rtn(c & ~3, 2u << (sh[u] & 31));
-                    const uint32_t nacc = acc + fs;
-                    c += nacc < acc ? d1 : d0;
-                    acc = nacc;
+                    for (int u = 0; u < LCH; ++u) {
+                        sh[u] = c << 3;
+                        ret[u] = ev_lds_add_rtn(c & ~3, 2u << (sh[u] & 31));
+                        const uint32_t nacc = acc + fs;
+                        c += nacc < acc ? d1 : d0;
+                        acc = nacc;
+                    }
                 }
-                fetch_item(q + EB / 64);
+                fetch_item(qn);
+                const int g = draw_begin();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): one wait, then the sixteen answers
+                const int qnn = UNI(g);
+                if (b >= 0) {
+                    uint32_t m = 0;
 #pragma unroll
-                for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit(ret[u] >> (sh[u] & 31), m, 1);
-                if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
+                    for (int u = 0; u < LCH; ++u) m = __builtin_amdgcn_alignbit(ret[u] >> (sh[u] & 31), m, 1);
+                    if (m) log_events(m, b, j0, ev_lo, ev_hi, gx_base, !whole);
+                }
+                q = qn; qn = qnn;
             }
         }
         BAR_LDS();
@@ -1031,6 +1048,9 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
         if (tid == 0) atomicAdd(&v.stats[ST_SLOW_CELLS], (unsigned long long)NR);
     }
     STAMP(7);
+#if defined(RBPF_STAMPS) && defined(EV_BARRIER_WAITS)
+    if (p == 0 && lane == 0) printf("wave %2d: %6lld cycles at %d barriers of %lld: %d %d %d %d %d %d %d %d\n", wave, bar_wait, bar_n, clock64() - t_begin, bar_w[0], bar_w[1], bar_w[2], bar_w[3], bar_w[4], bar_w[5], bar_w[6], bar_w[7]);
+#endif
     if (tid == 0) {
         if (s_cells) atomicAdd(&v.stats[ST_RAY_CELLS], s_cells);
         if (s_written) atomicAdd(&v.stats[ST_CELLS_WRITTEN], (unsigned long long)s_written);
