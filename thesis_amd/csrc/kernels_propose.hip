@@ -161,16 +161,18 @@ __global__ __launch_bounds__(256) void propose_samples_kernel(DevView v, Propose
     reinterpret_cast<float4*>(o + 192)[k] = make_float4((float)(cs * inv_cs), (float)(sn * inv_cs), (float)(g[0] * inv_cs + (double)off_x), (float)(g[1] * inv_cs + (double)off_y));
 }
 
-// ---- weighting: K gathers per beam (robot.py:118-139).  The samples of a beam end on neighbouring cells (one or two cache
-//      lines), so a beam's K look-ups are done together, eight at a time: eight cell addresses in the particle's home tile
-//      are formed without a branch, the eight byte loads are issued back to back, then added - nothing waits on a single
-//      load.  The address comes from SINGLE-precision arithmetic in home-tile cell coordinates.  Error budget, in cells,
-//      for |rotated beam| <= 1.5 dim and |result| < dim: the conversions of x, y, cos / cell, sin / cell cost
-//      4 * 1.5 dim * 2^-24, the offset's rounding dim * 2^-24, the two fused multiply-adds 2.5 dim * 2^-24 and
+// ---- weighting: K gathers per beam (robot.py:118-139).  A lane is a sample, 32 lanes one beam: the samples of a beam end
+//      on neighbouring cells, so the 64 byte loads of an instruction fall into a dozen cache lines; a lane does eight beams
+//      at a time - eight cell addresses in the particle's home tile formed without a branch, the eight byte loads issued
+//      back to back, then added.  The address comes from SINGLE-precision arithmetic in home-tile cell coordinates (the fused
+//      multiply-adds are exact in the sense of the budget below whether they are packed two beams to an instruction or not).
+//      Error budget, in cells, for |rotated beam| <= 1.5 dim and |result| < dim: the conversions of x, y, cos / cell,
+//      sin / cell cost 4 * 1.5 dim * 2^-24, the offset's rounding dim * 2^-24, the two fused multiply-adds 2.5 dim * 2^-24 and
 //      dim * 2^-24: 9.5 dim * 2^-24 = 4.5e-4 at dim = 800, 1.2e-3 at 2048.  The address is taken only when the point lies
 //      more than WSAFE (1e-3 for dim <= 1024, else 2e-3) inside its cell on both axes: the cell index is then the
-//      reference's (gridmap.py:119-128 on the float64 point).  The other 0.4 - 0.8 % of the look-ups are redone in float64
-//      the reference's way (lookup_cell_home) once the beam's fast ones are out.
+//      reference's (gridmap.py:119-128 on the float64 point).  The other 0.4 - 0.8 % of the look-ups - and every look-up of a
+//      beam outside the budget's premise, NaN in the host's list - are redone in float64 the reference's way
+//      (lookup_cell_home) from a queue, after the fast ones.
 //      Shared by propose_weight_kernel (every scan step) and weight_samples_product_kernel (rbpf_weight_samples: the
 //      per-sample test entry), so that the tests of the entry are tests of the product's look-ups.
 struct WeightFrame {
