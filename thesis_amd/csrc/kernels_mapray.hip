@@ -173,7 +173,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     __shared__ int s_need[49], s_tab[49];
     __shared__ int s_fan[4];
     __shared__ int s_wsum[RB / 64];
-    __shared__ int s_nslow, s_written, s_nspec, s_nact, s_exact, s_nnear, s_npool;
+    __shared__ int s_nslow, s_written, s_nspec, s_nact, s_exact, s_nnear, s_npool, s_wbq;
     __shared__ int s_lcnt[MAXLEV + 1], s_lfill[MAXLEV + 1], s_nk[MAXLEV + 2], s_lp[MAXLEV + 3], s_nlev;
     __shared__ unsigned long long s_cells;
     __shared__ double s_sincos[2];
@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 cnt8[(sgx - gx_base) * stride + (sgy - gy_base)] = (ix | iy) ? (uint8_t)0 : (uint8_t)(0x80u | ov);
             }
         }
+        if (tid == 0) s_wbq = 0;
         BAR_LDS();
         STAMP(6);
         // ---- write-back: one read-modify-write per touched 32-cell group of storage cells, tile by tile ----
@@ -1263,6 +1264,10 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
             const uint32_t kb1 = (uint32_t)(128 + v.cc.vmin) * 0x01010101u;             // byte-wise: (cell ^ 0x80) - kb1 = cell - vmin
             const uint32_t oadd = (uint32_t)(127 - (v.cc.thr - v.cc.vmin)) * 0x01010101u; // bit 7 of (R + oadd) = cell > thr
             const int gpt = v.dim >> 5;                                                // 32-cell groups per tile row
+            // waves draw batches of 64 items (32-cell groups) from a queue (as kernels_mapev.hip: the rows at a fan's rim hold few
+            // touched groups, a fixed share per wave leaves the workgroup waiting for its slowest wave)
+            auto next_batch = [&]() -> int { int g = 0; if (lane == 0) g = atomicAdd(&s_wbq, 1); return UNI(g); };
+            int batch = next_batch(), batch0 = 0;
             for (int a = S0 / v.dim; a <= S1 / v.dim; ++a)
             for (int bt = T_lo / v.dim; bt <= T_hi / v.dim; ++bt) {
                 if (a >= v.L || bt >= v.L || !s_need[a * v.L + bt]) continue;          // uniform
@@ -1273,8 +1278,12 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                 const int ngr = g_hi - g_lo + 1, items = (sr_hi - sr_lo + 1) * ngr;
                 int8_t* __restrict__ tile_base = v.pool + (size_t)tile * v.dim * v.dim;
                 int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
-                for (int it = tid; it < items; it += RB) {
-                    const int rr = it / ngr, gg = it - rr * ngr;
+                const int nbatch = (items + 63) >> 6;
+                const float inv_ngr = 1.0f / (float)ngr;
+                for (; batch < batch0 + nbatch; batch = next_batch()) {
+                    const int it = ((batch - batch0) << 6) + lane;
+                    if (it >= items) continue;
+                    const int rr = (int)(((float)it + 0.5f) * inv_ngr), gg = it - rr * ngr;   // it / ngr (kernels_mapev.hip has the error bound)
                     const int srow = sr_lo + rr, Gy = g_lo + gg;
                     const int ia = srow - C - fxl;                                     // source rows a (if not glitched), a + 1 (if glitched)
                     const bool va = !gxb[ia], vb = gxb[ia + 1];
@@ -1357,6 +1366,7 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
                     v.occ[((size_t)tile * v.dim + row_t) * v.ow + (col_t >> 5)] = occ;
                     bx0 = min(bx0, row_t); bx1 = max(bx1, row_t);
                 }
+                batch0 += nbatch;
                 bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
                 if (lane == 0 && bx1 >= 0) {                                           // this workgroup is the tile's only writer
                     atomicMin(&v.tile_bbox[4 * tile + 0], bx0); atomicMax(&v.tile_bbox[4 * tile + 1], bx1);
