@@ -160,3 +160,49 @@ def test_fans_larger_than_the_lds_window_run_in_strips(monkeypatch):
     assert c["window_fallbacks"] == 0 and c["fallback_geometry"] == 0 and c["fallback_bound"] == 0
     assert c["map_windows"] >= 2 * P * n_scans                               # several strips per particle and scan
     e.close()
+
+
+def test_config2_map_update_of_a_particle_depends_on_its_pose_alone():
+    """BASELINE configs[2] at full size (4096 particles x 1081 beams, 0.05 m), a property no oracle run is needed for: the
+    map a particle gets depends on ITS pose and the scans only (hybridmap.py:95-145 is a method of one map).  Two engines
+    get the same 4096 poses in opposite order for three scans; particle i of the first must hold the tiles of particle
+    4095 - i of the second, cell for cell - 4096 workgroups share the tile pool, its allocator and the LDS-window chain,
+    and nothing of that may leak between particles.  64 particles are read back and compared, eight of them also against
+    the C oracle; the counters of both runs (ray cells, cells written) must agree exactly."""
+    from thesis_amd.engine import ParticleEngine
+    from thesis_amd.datasets import synthetic
+    P, B, cs = 4096, 1081, 0.05
+    angles, ranges, _, truth = synthetic.make_log(4, B, period=0.1)
+    rng = np.random.Generator(np.random.PCG64(4096))
+    poses = [np.asarray(truth[k]) + rng.normal(0, [0.15, 0.15, 0.03], size=(P, 3)) for k in range(3)]
+    runs = []
+    for flip in (False, True):
+        e = ParticleEngine(P, max_beams=B, cell_size=cs, pool_tiles=P + 64)
+        for k in range(3):
+            e.set_scan(ranges[k], angles)
+            e.map_update(poses[k][::-1].copy() if flip else poses[k])
+        runs.append(e)
+    a, b = runs
+    ca, cb = a.counters(), b.counters()
+    assert ca["ray_cells_visited"] == cb["ray_cells_visited"] and ca["cells_written"] == cb["cells_written"] > 0
+    assert ca["window_fallbacks"] == cb["window_fallbacks"]
+    picks = rng.choice(P, size=64, replace=False)
+    lib = c_oracle.load()
+    for n, i in enumerate(picks):
+        ta = {c: t for c, t in a.tiles(int(i))}
+        tb = {c: t for c, t in b.tiles(int(P - 1 - i))}
+        assert ta.keys() == tb.keys() and sum(int(np.count_nonzero(t)) for t in ta.values()) > 20000      # (a 16 m room at 0.05 m)
+        for c in ta:
+            assert np.array_equal(ta[c], tb[c]), f"particle {i}: tile {c} differs between the two orders"
+        if n < 8:                                            # and they are the reference's cells
+            m = c_oracle.CMap(lib, cs)
+            x, y = ranges[0] * np.cos(angles), ranges[0] * np.sin(angles)
+            for k in range(3):
+                x, y = ranges[k] * np.cos(angles), ranges[k] * np.sin(angles)
+                m.update(poses[k][i], x, y)
+            want = _oracle_dump(m)
+            got = {c: t for c, t in ta.items() if np.any(t)}
+            assert set(got) == {c for c, t in want.items() if np.any(t)}
+            for c in got:
+                assert np.array_equal(got[c], want[c])
+    a.close(); b.close()
