@@ -168,7 +168,8 @@ def test_config2_map_update_of_a_particle_depends_on_its_pose_alone():
     get the same 4096 poses in opposite order for three scans; particle i of the first must hold the tiles of particle
     4095 - i of the second, cell for cell - 4096 workgroups share the tile pool, its allocator and the LDS-window chain,
     and nothing of that may leak between particles.  64 particles are read back and compared, eight of them also against
-    the C oracle; the counters of both runs (ray cells, cells written) must agree exactly."""
+    the C oracle; the counters of both runs (ray cells, cells written) must agree exactly.  The sample weights of a fourth
+    scan (4096 x 30 samples, the product's look-ups) are mirrored too, bit for bit, and the oracle's for the eight."""
     from thesis_amd.engine import ParticleEngine
     from thesis_amd.datasets import synthetic
     P, B, cs = 4096, 1081, 0.05
@@ -183,6 +184,14 @@ def test_config2_map_update_of_a_particle_depends_on_its_pose_alone():
             e.map_update(poses[k][::-1].copy() if flip else poses[k])
         runs.append(e)
     a, b = runs
+    # the sample weights of the next scan (robot.py:118-139) on those maps, K = 30 samples round every particle's last pose
+    K = 30
+    guesses = poses[2][:, None, :] + rng.normal(0, [0.04, 0.04, 0.015], size=(P, K, 3))
+    prs = rng.uniform(0.5, 2.0, size=(P, K))
+    a.set_scan(ranges[3], angles); b.set_scan(ranges[3], angles)
+    wa = a.weight_samples(guesses, prs)
+    wb = b.weight_samples(guesses[::-1].copy(), prs[::-1].copy())
+    assert np.array_equal(wa, wb[::-1]) and np.all(np.isfinite(wa))
     ca, cb = a.counters(), b.counters()
     assert ca["ray_cells_visited"] == cb["ray_cells_visited"] and ca["cells_written"] == cb["cells_written"] > 0
     assert ca["window_fallbacks"] == cb["window_fallbacks"]
@@ -205,4 +214,7 @@ def test_config2_map_update_of_a_particle_depends_on_its_pose_alone():
             assert set(got) == {c for c, t in want.items() if np.any(t)}
             for c in got:
                 assert np.array_equal(got[c], want[c])
+            x3, y3 = ranges[3] * np.cos(angles), ranges[3] * np.sin(angles)
+            ww = np.asarray(m.sample_weight(guesses[i], x3, y3, prs[i]), dtype=np.float64)
+            assert np.max(np.abs(wa[i] - ww) / np.maximum(1.0, np.abs(ww))) < 1e-12
     a.close(); b.close()
