@@ -22,6 +22,8 @@
 //   * dim need not be a multiple of 32 (0.1 m cells: dim 400): the last 32-cell group of a tile row is partial.
 //
 //   Reference: hybridmap.py:95-145 (update), :274-301 (Bresenham), gridmap.py:86-117 (clamped adds).
+#include <hip/hip_ext.h>
+
 #include "rbpf_mapupdate.h"
 
 namespace rbpf {
@@ -1054,11 +1056,14 @@ __global__ __launch_bounds__(EB) void map_update_ev_kernel(DevView v) {
     }
 }
 
-void launch_map_update_ev(const DevView& v, hipStream_t s) {
+// t0 / t1 (or nullptr): timing events that take the kernel's own start and end (hipExtLaunchKernelGGL: the dispatch carries
+// them, no event records - and their barriers - in the stream)
+void launch_map_update_ev(const DevView& v, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     const EvGeom g = ev_geom(v.B, v.reach);
     static size_t lds_set[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_ev_kernel), (size_t)g.bytes, lds_set);
-    hipLaunchKernelGGL(map_update_ev_kernel, dim3(v.P), dim3(EB), (size_t)g.bytes, s, v);
+    if (t0 && t1) hipExtLaunchKernelGGL(map_update_ev_kernel, dim3(v.P), dim3(EB), (size_t)g.bytes, s, t0, t1, 0, v);
+    else hipLaunchKernelGGL(map_update_ev_kernel, dim3(v.P), dim3(EB), (size_t)g.bytes, s, v);
 }
 
 }  // namespace rbpf

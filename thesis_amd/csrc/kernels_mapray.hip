@@ -23,6 +23,8 @@
 //   * A fan larger than the LDS window is processed in strips of storage rows (one launch, any fan size): cell sizes
 //     of 0.025 m and 15 m rays included.  8-bit counters cannot overflow: a bound on the hits of any cell with j >= 16
 //     is checked from the slope buckets first (cells nearer than NEAR_R steps live in a 16-bit block).
+#include <hip/hip_ext.h>
+
 #include "rbpf_mapupdate.h"
 
 namespace rbpf {
@@ -1390,11 +1392,12 @@ __global__ __launch_bounds__(RB) void map_update_ray_kernel(DevView v, const int
     }
 }
 
-void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s) {
+void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {   // t0 / t1: as launch_map_update_ev
     const RayGeom g = ray_geom(v.B, v.reach);
     static size_t lds_set[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_ray_kernel), (size_t)g.bytes, lds_set);
-    hipLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, v, only);
+    if (t0 && t1) hipExtLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, t0, t1, 0, v, only);
+    else hipLaunchKernelGGL(map_update_ray_kernel, dim3(v.P), dim3(RB), (size_t)g.bytes, s, v, only);
 }
 
 }  // namespace rbpf

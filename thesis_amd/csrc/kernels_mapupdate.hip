@@ -716,21 +716,29 @@ __global__ __launch_bounds__(MU_BLOCK, 4) void map_update_kernel(DevView v, cons
     }
 }
 
-void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s) {
+// the first kernel of the chain for this engine: 0 none (128x128 windows for every particle), 1 the event walk, 2 the global-index kernel
+int map_update_first_kernel(const DevView& v) {
+    // Default first kernel: the event walk (kernels_mapev.hip) on grids of 0.04 m and coarser, where a fan usually fits its one LDS
+    // window; on finer grids every fan takes three or four strips, and there the global-index kernel of round 2 (kernels_mapray.hip:
+    // no returning adds, a leaner strip set-up) is a quarter faster (8192 x 181 beams x 0.025 m: 0.82 against 1.02 ms per 2048).
+    const bool ev_ok = map_update_ev_available(v), ray_ok = map_update_ray_available(v);
+    const bool ev_first = v.mu_mode == 5 || (v.mu_mode == 0 && (v.dim <= 1024 || !ray_ok));
+    if (ev_first && ev_ok) return 1;
+    if ((v.mu_mode == 0 || v.mu_mode == 3) && ray_ok) return 2;
+    if (v.mu_mode == 0 && ev_ok) return 1;
+    return 0;
+}
+
+// t0 / t1 (or nullptr): timing events for the FIRST kernel's own start and end (ignored when there is none)
+void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     size_t lds = raycast_lds_bytes(v.B, v.reach);
     static size_t lds_set[MAX_DEVICES] = {};   // more than the default 64 KiB of dynamic LDS
     ensure_dynamic_lds(reinterpret_cast<const void*>(map_update_kernel), lds, lds_set);
     // the chain: the first kernel leaves mu_fallback[p] != 0 for the particles it could not hold, the window kernel takes those
-    // Default first kernel: the event walk (kernels_mapev.hip) on grids of 0.04 m and coarser, where a fan usually fits its one LDS
-    // window; on finer grids every fan takes three or four strips, and there the global-index kernel of round 2 (kernels_mapray.hip:
-    // no returning adds, a leaner strip set-up) is a quarter faster (8192 x 181 beams x 0.025 m: 0.82 against 1.02 ms per 2048).
-    bool fan = false;
-    const bool ev_ok = map_update_ev_available(v), ray_ok = map_update_ray_available(v);
-    const bool ev_first = v.mu_mode == 5 || (v.mu_mode == 0 && (v.dim <= 1024 || !ray_ok));
-    if (ev_first && ev_ok) { launch_map_update_ev(v, s); fan = true; }
-    else if ((v.mu_mode == 0 || v.mu_mode == 3) && ray_ok) { launch_map_update_ray(v, nullptr, s); fan = true; }
-    else if (v.mu_mode == 0 && ev_ok) { launch_map_update_ev(v, s); fan = true; }
-    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, fan ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, d_bad);
+    const int first = map_update_first_kernel(v);
+    if (first == 1) launch_map_update_ev(v, s, t0, t1);
+    else if (first == 2) launch_map_update_ray(v, nullptr, s, t0, t1);
+    hipLaunchKernelGGL(map_update_kernel, dim3(v.P), dim3(MU_BLOCK), lds, s, v, first ? (const int32_t*)v.mu_fallback : (const int32_t*)nullptr, d_bad);
 }
 
 }  // namespace rbpf

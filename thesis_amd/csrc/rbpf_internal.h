@@ -159,14 +159,15 @@ namespace rbpf {
 void launch_weight_samples(const DevView& v, const double* d_guesses, const double* d_prs, int K,
                            double* d_out_w, hipStream_t s);
 void launch_weight_samples_product(const DevView& v, const double* d_guesses, const double* d_prs, int K, double* d_out_w, hipStream_t s);
-void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s);   // picks the kernel(s) below; d_bad: NaN-branch weight increments after the update (or nullptr)
+int map_update_first_kernel(const DevView& v);   // 0 none, 1 event walk, 2 global-index kernel
+void launch_map_update_fused(const DevView& v, const uint8_t* d_bad, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);   // picks the kernel(s) below; d_bad: NaN-branch weight increments after the update (or nullptr)
 void launch_ingest(const void* mapped_src, void* d_dst, size_t bytes, hipStream_t s);   // bytes rounded up to 16
 void launch_ingest2(const int32_t* mapped_a, int32_t* d_a, const int32_t* mapped_b, int32_t* d_b, int n, hipStream_t s);
 void launch_readback(void* mapped_dst, const double* d_nan_elem, const int32_t* d_did, const int32_t* d_idx, int n, hipStream_t s);
 bool map_update_ray_available(const DevView& v);
-void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s);
+void launch_map_update_ray(const DevView& v, const int32_t* only, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 bool map_update_ev_available(const DevView& v);
-void launch_map_update_ev(const DevView& v, hipStream_t s);
+void launch_map_update_ev(const DevView& v, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_get_odds(const DevView& v, int particle, const double* d_xy, int n, double* d_vals,
                      uint8_t* d_none, hipStream_t s);
 void launch_last_scan(const DevView& v, int particle, double* d_out_xy, hipStream_t s);
