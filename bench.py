@@ -337,7 +337,8 @@ def main():
                 "cell_bytes_algorithmic": 4, "cell_bytes_stored": 1,
                 "achieved_stored_bytes_GBs": ach / 4.0,
                 "kernel_ms_mean": mean_ms,
-                "kernel_ms_source": f"{dominant}: HIP events in the timed region; the others: HIP events in untimed steps "
+                "kernel_ms_source": f"{dominant}: HIP events in the timed region (raycast: the events ride on the first map kernel's dispatch "
+                                    "and take its own start and end); the others: HIP events round the family's launches in untimed steps "
                                     "(after the timed region on one GPU, the warm-up steps otherwise)",
                 "slow_cells_per_step": c["slow_cells"] / n_upd,
                 "ndt": {"enabled": bool(args.ndt), "runs_per_step": c["ndt_runs"] / n_upd,
