@@ -27,6 +27,8 @@
 #include <limits.h>
 #include <string.h>
 
+#include <hip/hip_ext.h>
+
 #include "rbpf_internal.h"
 #include "rbpf_device.h"
 
@@ -1082,28 +1084,32 @@ int match_per_rot(double max_range_m, double mcs) {          // coarse candidate
     return (2 * k + 1) * (2 * k + 1);
 }
 
-static void launch_match(const DevView& v, const MatchArgs& a_in, int grid, size_t lds, hipStream_t s) {
+// t0 / t1 (or nullptr): timing events that take the kernel's own start and end (carried by its dispatch: hipExtLaunchKernelGGL)
+static void launch_match(const DevView& v, const MatchArgs& a_in, int grid, size_t lds, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     MatchArgs a = a_in;
     a.sc_cap = match_sc_capacity(a.N, a.cap_sel, lds);
     static size_t lds_set[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(match_kernel), lds, lds_set);
-    hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, v, a);
+    if (t0 && t1) hipExtLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, t0, t1, 0, v, a);
+    else hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(MBLOCK), lds, s, v, a);
 }
 
 // NDT cell edge in matcher cells for matchScanCustom.m:37 ('CellSize', 0.1)
 int ndt_cells(double mcs) { return (int)floor(0.1 / mcs + 0.5); }
 
-static void launch_ndt(const DevView& v, const MatchArgs& a, int grid, hipStream_t s) {
+static void launch_ndt(const DevView& v, const MatchArgs& a, int grid, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     size_t lds = ndt_lds_bytes(a.N, a.cap_sel);
     static size_t lds_set[MAX_DEVICES] = {};
     ensure_dynamic_lds(reinterpret_cast<const void*>(ndt_kernel), lds, lds_set);
-    hipLaunchKernelGGL(ndt_kernel, dim3(grid), dim3(NBLOCK), lds, s, v, a);
+    if (t0 && t1) hipExtLaunchKernelGGL(ndt_kernel, dim3(grid), dim3(NBLOCK), lds, s, t0, t1, 0, v, a);
+    else hipLaunchKernelGGL(ndt_kernel, dim3(grid), dim3(NBLOCK), lds, s, v, a);
 }
 
 // stage 1: the grid search (match_kernel); stage 2: the NDT refinement (ndt_kernel) -- two calls so that the host can
 // time them apart.  Returns whether the NDT stage is active for this configuration.
 bool launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
-                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, int stage, hipStream_t s) {
+                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, int stage, hipStream_t s,
+                            hipEvent_t t0, hipEvent_t t1) {
     MatchArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = mode; a.single = 0; a.ref_xy = d_ref; a.n_ref = n_ref; a.out = d_out;
@@ -1114,8 +1120,8 @@ bool launch_match_particles(const DevView& v, int mode, const double* d_ref, int
     a.dup_of = v.dups_valid ? v.dup_of : nullptr;
     const bool ndt = a.ndt && a.ndt_nc >= 2 && v.ndt_occ;
     if (ndt) { a.ndt_occ = v.ndt_occ; a.ndt_aux = v.ndt_aux; }
-    if (stage == 1) launch_match(v, a, v.P, lds, s);
-    if (stage == 2 && ndt) launch_ndt(v, a, v.P, s);
+    if (stage == 1) launch_match(v, a, v.P, lds, s, t0, t1);
+    if (stage == 2 && ndt) launch_ndt(v, a, v.P, s, t0, t1);
     return ndt;
 }
 

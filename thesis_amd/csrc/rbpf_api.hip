@@ -620,15 +620,17 @@ static int run_matcher(rbpf_handle* h, int32_t adj, const double* last_scan_xy, 
         HIP_TRY(h, hipMemcpyAsync(h->d_last_xy, slot, (size_t)n_last * 16, hipMemcpyHostToDevice, h->stream));
         h->ring_last.submitted(h->stream);
     }
-    h->prof_begin(3);
+    // both stages are one kernel each: their timing events ride on the dispatch and take the kernel's own start and end
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    auto take_events = [&](int k) { t0 = t1 = nullptr; if (!((h->prof_mask >> k) & 1u)) return; const int slot = h->ring_n[k] % rbpf_handle::RING;
+                                    t0 = h->ring[k][0][slot]; t1 = h->ring[k][1][slot]; h->begin_used[k][slot] = t0; h->last_end = nullptr; h->ring_n[k]++; };
+    take_events(3);
     const bool ndt = launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
-                                            h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 1, h->stream);
-    h->prof_end(3);
+                                            h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 1, h->stream, t0, t1);
     if (ndt) {
-        h->prof_begin_chained(4);
+        take_events(4);
         launch_match_particles(v, adj ? 1 : 0, h->d_last_xy, adj ? n_last : 0, h->d_match, h->mN, h->mds, h->mmcs, h->md0,
-                               h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 2, h->stream);
-        h->prof_end(4);
+                               h->mncr, h->cfg.match_max_range, h->cfg.max_beams, h->mlds, 2, h->stream, t0, t1);
     }
     HIP_TRY(h, hipGetLastError());
     return RBPF_OK;

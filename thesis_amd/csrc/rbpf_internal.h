@@ -196,7 +196,8 @@ int ndt_cells(double mcs);
 void match_geometry(const rbpf_config& c, double cell_size, int& N, int& ds, double& mcs, double& d0, int& n_coarse_rot);
 int match_max_coarse(int n_coarse_rot, double max_range_m, double mcs);
 bool launch_match_particles(const DevView& v, int mode, const double* d_ref, int n_ref, double* d_out, int N, int ds,
-                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, int stage, hipStream_t s);
+                            double mcs, double d0, int ncr, double max_range, int cap_sel, size_t lds, int stage, hipStream_t s,
+                            hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);   // t0 / t1: timing events carried by the stage's kernel dispatch
 void launch_match_single(const DevView& v, const double* d_ref, int n_ref, const double* guess3, const double* range3,
                          const float* d_sel_x, const float* d_sel_y, int n_sel, double* d_out, int N, int ds, double mcs,
                          double d0, int ncr, int cap_sel, size_t lds, uint32_t* d_ndt_occ, double* d_ndt_aux, hipStream_t s);
