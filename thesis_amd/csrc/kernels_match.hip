@@ -611,8 +611,13 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
                         const int i0 = in ? u * W + (w0 >> 5) : 0;
                         sh[k] = w0 & 31;
                         const bool two = in && sh[k] > 23 && (w0 >> 5) + 1 < W;
+#ifdef FINE_ABLATE_LDS     // diagnostic: half of the fine level's LDS reads (wrong scores)
+                        ol[k] = in ? s.occ[i0] : 0u; dl[k] = ol[k];
+                        oh[k] = 0u; dh[k] = 0u; (void)two;
+#else
                         ol[k] = in ? s.occ[i0] : 0u; dl[k] = in ? s.dil[i0] : 0u;
                         oh[k] = two ? s.occ[i0 + 1] : 0u; dh[k] = two ? s.dil[i0 + 1] : 0u;
+#endif
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
