@@ -589,7 +589,9 @@ __global__ __launch_bounds__(MBLOCK) void match_kernel(DevView v, MatchArgs a) {
         const int NS = 6;                                           // 9 * 9 * 6 = 486 items for 512 threads
         const int per = (((n4 + NS - 1) / NS) + 3) & ~3;
         for (int item = tid; item < FR * FT * NS; item += MBLOCK) {
-            const int sl = item % NS, ix = (item / NS) % FT - M_FINE_T, ir = item / (NS * FT) - M_FINE_R;
+            // (x translation slowest: the nine x translations of a beam read rows u .. u + 8 of one column word - two LDS banks - and
+            // must not sit in the lanes of one wave)
+            const int sl = item % NS, ir = (item / NS) % FR - M_FINE_R, ix = item / (NS * FR) - M_FINE_T;
             const double dth = (double)(cir * M_COARSE + ir) * a.d0;
             float sn, cs;
             __sincosf(gthf + (float)dth, &sn, &cs);
